@@ -1,0 +1,27 @@
+# Top-level build: product libraries, oracle (test infrastructure) and the test-only host emulation.
+#   make            everything
+#   make product    librt_mi355.so (HIP, gfx950) + libraytracer_host.so (reference host API)
+#   make oracle     oracle/liboracle.so and, where /root/reference exists, oracle/_ref/libref.so
+CXX ?= g++
+
+all: product oracle emul
+
+product:
+	$(MAKE) -C raytracer_amd/csrc
+	$(MAKE) -C raytracer_amd/host
+
+oracle:
+	$(MAKE) -C oracle
+
+emul: tests/host_emul/libemul.so
+
+tests/host_emul/libemul.so: tests/host_emul/emul.cpp raytracer_amd/csrc/rt_pixel.h raytracer_amd/csrc/rt_pack.h raytracer_amd/csrc/rt_exact.h raytracer_amd/csrc/rt_layout.h include/rt_mi355.h
+	$(CXX) -O2 -std=c++17 -ffp-contract=off -fopenmp -fPIC -shared -Wall -Wextra -o $@ tests/host_emul/emul.cpp -lm
+
+clean:
+	$(MAKE) -C raytracer_amd/csrc clean
+	$(MAKE) -C raytracer_amd/host clean
+	$(MAKE) -C oracle clean
+	rm -f tests/host_emul/libemul.so
+
+.PHONY: all product oracle emul clean

@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Mrays/s (primary + shadow) on the reference's drone / treasure /
+ground scene at 1920x1080, one ray per pixel plus one shadow ray per hit pixel.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one frame.  Rank r of N renders frames r, r+N, r+2N, ... of the 96-frame animation
+(per-GPU work is fixed as N grows: weak scaling); for N > 1 the finished RGB8 framebuffers are
+gathered to rank 0 over RCCL inside the timed region, in batches that travel while the next
+batch renders.  Framebuffers stay in HBM; nothing is copied to the host inside the timed region.
+
+A ray is one camera ray or one shadow ray tested against the whole scene (all meshes):
+rays per frame = pixels + pixels that hit something.
+
+Rank 0 prints one JSON line.  Besides the throughput it carries
+  roofline      the render kernel against the HBM roofline: algorithmic bytes of the reference's
+                traversal (32 B per box test, 36 B per triangle test, 64 B per hit pixel for
+                attributes + texel, 3 B per pixel stored) over the kernel's mean duration measured
+                with HIP events on its stream; plus the same for FP32 VALU work
+  cpu_baseline  the compiled reference functions (or, without them, the CPU restatement) timed on
+                the host cores on a bounded sample of the same workload (N = 1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+VALU_PEAK_TFLOPS = 157.3       # MI355X FP32 vector peak
+# Algorithmic bytes / flops of the reference's traversal.
+B_SLAB, B_TRI, B_HIT, B_PIXEL = 32, 36, 64, 3
+F_SLAB, F_TRI, F_XFORM = 22, 50, 45
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=48)
+    p.add_argument("--warmup", type=int, default=8)
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--batch", type=int, default=4, help="frames per gather message (N > 1)")
+    p.add_argument("--variant", type=int, default=-1)
+    p.add_argument("--block", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-frames", type=int, default=8)
+    return p.parse_args()
+
+
+def cpu_baseline(width, height, n_frames):
+    """Times the CPU path on the host cores: frames 0..n-1 of the animation at the bench size."""
+    from oracle import pyoracle as po
+    meshes = po.default_meshes()
+    cam, light = po.default_camera(), po.default_light()
+    use_ref = po.ref_available()
+    if use_ref:
+        soups = [po.load_obj(os.path.join(po.ASSETS, n + ".obj")) for n in ("drone", "treasure", "ground")]
+        scene = po.RefScene(soups, [m.rgba for m in meshes])
+        threads = po.ref().refc_max_threads()
+        run = lambda f: scene.render(po.animation_transforms(f), cam, light, width, height)          # noqa: E731
+    else:
+        threads = po.lib().orc_max_threads()
+        run = lambda f: po.render_frame(meshes, po.animation_transforms(f), cam, light, width, height)   # noqa: E731
+    run(0)                                                   # warm-up
+    rays, t0 = 0, time.perf_counter()
+    for f in range(n_frames):
+        fr = run(f)
+        rays += width * height + int((fr.hit_id >= 0).sum())
+    dt = time.perf_counter() - t0
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(threads),
+            "kind": "reference" if use_ref else "port",
+            "sample": f"frames 0..{n_frames - 1} of the animation at {width}x{height}, "
+                      f"{'compiled reference functions (gcc -O3 -ffp-contract=off) + composition loop' if use_ref else 'CPU restatement'}, "
+                      f"OpenMP dynamic rows, {threads} threads, {dt:.1f} s",
+            "ms_per_frame": round(dt / n_frames * 1e3, 2)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the rendering core has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from raytracer_amd import demo, sharding
+    scene = demo.DemoScene(local)
+    ctx = scene.ctx
+    if a.variant >= 0:
+        ctx.set_option("variant", a.variant)
+    if a.block:
+        ctx.set_option("block", a.block)
+    W, H = a.width, a.height
+    NF = demo.N_FRAMES
+    # An explicit stream, made torch's current one: the kernels are launched on it, and RCCL orders
+    # its gathers after the work already queued on the current stream.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    sptr = stream.cuda_stream
+
+    # frames this rank renders, in order; wraps around the animation if steps exceed its share
+    share = sharding.frames_for_rank(NF, rank, world) or [rank % NF]
+    seq = [share[i % len(share)] for i in range(a.warmup + a.steps)]
+
+    # ---- untimed: rays and reference-equivalent work of every distinct frame of this rank
+    hit_id = torch.empty((H, W), dtype=torch.int32, device=dev)
+    scratch = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    info = {}
+    from raytracer_amd import capi
+    for f in sorted(set(seq[a.warmup:])):
+        scene.render(f, W, H, scratch, hit_id=hit_id, flags=capi.RT_FLAG_COUNT_WORK | capi.RT_FLAG_REFERENCE_ORDER, stream=sptr)
+        stream.synchronize()
+        info[f] = ctx.last_counters()
+        assert info[f]["hit_pixels"] == int((hit_id >= 0).sum().item())
+    ctx.set_option("timing", 0)
+
+    # ---- warm-up
+    nb = (a.steps + a.batch - 1) // a.batch
+    bufs = [torch.empty((a.batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(nb)]
+    for i in range(a.warmup):
+        scene.render(seq[i], W, H, bufs[0][i % a.batch], stream=sptr)
+    if world > 1:
+        g = sharding.FrameGather(rank, world)
+        g.submit(bufs[0])
+        g.finish()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+
+    # ---- timed region: exactly `steps` frames
+    gather = sharding.FrameGather(rank, world) if world > 1 else None
+    if gather is not None:
+        gather.prealloc(nb, bufs[0])
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        b, k = divmod(i, a.batch)
+        scene.render(seq[a.warmup + i], W, H, bufs[b][k], stream=sptr)
+        if gather is not None and (k == a.batch - 1 or i == a.steps - 1):
+            gather.submit(bufs[b])
+    if gather is not None:
+        gather.finish()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+
+    rays_rank = sum(info[f]["primary_rays"] + info[f]["shadow_rays"] for f in seq[a.warmup:])
+    stats = torch.tensor([dt, float(rays_rank)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rsum = stats[1:].clone()
+        dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+        dt_all, rays_all = float(tmax.item()), float(rsum.item())
+    else:
+        dt_all, rays_all = dt, float(rays_rank)
+
+    # ---- kernel duration with HIP events on the launch stream (rank 0), one launch at a time
+    roof = None
+    if rank == 0:
+        ctx.set_option("timing", 1)
+        ms, alg_bytes, alg_flops = [], [], []
+        for f in seq[a.warmup:]:
+            scene.render(f, W, H, bufs[0][0], stream=sptr)
+            ms.append(ctx.last_kernel_ms())
+            c = info[f]
+            rays = c["primary_rays"] + c["shadow_rays"]
+            alg_bytes.append(c["slab_tests"] * B_SLAB + c["tri_tests"] * B_TRI + c["hit_pixels"] * B_HIT + W * H * B_PIXEL)
+            alg_flops.append(c["slab_tests"] * F_SLAB + c["tri_tests"] * F_TRI + rays * 3 * F_XFORM)
+        kern_ms = float(np.mean(ms))
+        gbs = float(np.mean(alg_bytes)) / (kern_ms * 1e-3) / 1e9
+        tfl = float(np.mean(alg_flops)) / (kern_ms * 1e-3) / 1e12
+        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "render kernel (variant %d, block %d)" % (ctx.get_option("variant"), ctx.get_option("block")),
+                "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(np.mean(alg_bytes)),
+                "valu": {"achieved": round(tfl, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tfl / VALU_PEAK_TFLOPS, 5)},
+                "note": "scene (77 KB of nodes, 170 KB of triangles) is cache resident: algorithmic bytes are "
+                        "served by L1/L2/LDS, not HBM; see DESIGN.md"}
+        tr = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                roof["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(W, H, a.cpu_frames)
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (primary+shadow), 1080p drone scene",
+            "value": round(rays_all / dt_all / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt_all / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "reference scene assets (drone/treasure/ground OBJ + WebP), animation frames of raytracer.c",
+            "config": {"workload": f"{W}x{H} frame, 1 primary ray/pixel + 1 shadow ray/hit pixel, 3 meshes (3625 triangles)",
+                       "frames_per_rank": a.steps, "sharding": "frame f on rank f mod N" if world > 1 else "single GPU",
+                       "gather": f"RGB8 framebuffers to rank 0 over RCCL, {a.batch} frames per message" if world > 1 else "none"},
+            "frames_per_s": round(a.steps * world / dt_all, 2),
+            "rays_per_frame": int(rays_rank / a.steps),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * rt_mi355.h -- C ABI of the MI355X rendering core (librt_mi355.so).
+ *
+ * This is the drop-in boundary for the reference ray tracer's per-pixel ray/scene loop.
+ * The reference has no FFI of its own: its public C headers are the interface, and its
+ * driver calls render_scene(Scene*) once per frame (reference raytracer.c:56, scene.h:34).
+ * A host that keeps the reference's structs binds the entry points below instead of
+ * running scene.c:52-160 on the CPU.  All structs are plain C, layout-identical to the
+ * reference structs they are named after, so reference-side pointers can be passed as is.
+ *
+ * Conventions: every function returns RT_OK (0) or a negative rt_status; nothing aborts.
+ * Pointers named d_* are DEVICE pointers (HBM of the context's GPU), h_* are host pointers.
+ * A context is bound to one GPU and is not thread-safe; use one context per host thread.
+ */
+#ifndef RT_MI355_H
+#define RT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,       /* bad argument (NULL, negative size, unknown id ...) */
+    RT_ERR_DEVICE = -2,        /* a HIP call failed; rt_last_error() has the text */
+    RT_ERR_NO_DEVICE = -3,     /* no usable GPU / device index out of range */
+    RT_ERR_UNSUPPORTED = -4,   /* input outside the supported envelope (limits below) */
+    RT_ERR_CAPACITY = -5       /* caller-provided output array too small */
+} rt_status;
+
+/* Limits of this build. */
+#define RT_MAX_MESHES        8          /* meshes per scene (one BVH each, reference scene.c:72) */
+#define RT_MAX_TREE_DEPTH    30         /* deepest BVH the traversal stack covers */
+#define RT_MAX_MESH_TRIS     (1 << 24)  /* triangles per mesh */
+
+/* ---- reference-layout structs ---------------------------------------------------------- */
+typedef struct { float x, y, z; } rt_vec3;                       /* math/vec3.h:6 */
+typedef struct { float u, v; } rt_vec2;                          /* math/vec3.h:7 */
+typedef struct { rt_vec3 position, rotation; } rt_transform;     /* math/ray.h:12-15 (Transform) */
+typedef struct { rt_vec3 position, look_at, up; float fov; } rt_camera;   /* render/camera.h:7-12 (Camera) */
+typedef struct { rt_vec3 direction, color; } rt_light;           /* render/light.h:6-9 (DirectionalLight);
+                                                                    direction already normalised (light.c:4) */
+typedef struct {                                                  /* geometry/triangle.h:6-10 (Triangle, 96 B) */
+    rt_vec3 v0, v1, v2;
+    rt_vec2 t0, t1, t2;
+    rt_vec3 n0, n1, n2;
+} rt_triangle;
+
+/* accel/bvh.h:8-14 (BVHNode) as the reference lays it out on LP64: a heap node with child
+ * pointers.  rt_bvh_flatten_tree() reads a tree of these in place. */
+typedef struct rt_tree_node {
+    rt_vec3 bounds_min, bounds_max;
+    struct rt_tree_node* left;
+    struct rt_tree_node* right;
+    int start_idx;
+    int triangle_count;
+} rt_tree_node;
+
+/* The same node with indices instead of pointers (-1 = no child).  nodes[0] is the root;
+ * a node is followed by its whole left subtree, then its whole right subtree. */
+typedef struct {
+    rt_vec3 bounds_min, bounds_max;
+    int32_t left, right;
+    int32_t start_idx, triangle_count;
+} rt_flat_node;
+
+typedef struct rt_ctx rt_ctx;                                     /* opaque */
+
+/* Work counters of one rt_render_frame call made with RT_FLAG_COUNT_WORK. */
+typedef struct {
+    uint64_t primary_rays, shadow_rays;     /* rays traced (a ray = one ray against the whole scene) */
+    uint64_t slab_tests, tri_tests;         /* ray/AABB and ray/triangle tests executed */
+    uint64_t hit_pixels, shadowed_pixels;
+} rt_counters;
+
+/* ---- context --------------------------------------------------------------------------- */
+/* Replaces nothing in the reference (it has no device); pairs with create_scene /
+ * destroy_scene (scene.c:8-29, 227-239) in a host binding. */
+int rt_ctx_create(int device, rt_ctx** out);
+int rt_ctx_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);                     /* text of the last failure ("" if none) */
+const char* rt_status_string(int status);
+
+/* ---- BVH build (host) ------------------------------------------------------------------ */
+/* create_bvh / create_bvh_node (accel/bvh.c:4-67): longest-axis, mean-of-centroids split,
+ * swap-to-front partition, leaves of <= 4 triangles.  Reorders tris IN PLACE exactly as the
+ * reference does (triangle indices reported by the renderer are indices into that order)
+ * and writes the flat node array.  cap >= 2*n is always enough. */
+int rt_bvh_build(rt_triangle* tris, int32_t n, rt_flat_node* nodes_out, int32_t cap, int32_t* n_nodes);
+/* Converts a reference pointer tree (Mesh.bvh.root, geometry/mesh.h:17) to the flat form. */
+int rt_bvh_flatten_tree(const rt_tree_node* root, rt_flat_node* nodes_out, int32_t cap, int32_t* n_nodes);
+
+/* ---- scene upload ---------------------------------------------------------------------- */
+/* Takes what create_mesh (geometry/mesh.c:6-119) leaves in a Mesh: the triangle array in
+ * post-build order, its BVH, and the WebPDecodeRGBA texture (row-major RGBA8).  Copies all of
+ * it to the GPU in the kernel's own layout; the host arrays may be freed afterwards.
+ * Meshes get ids 0,1,2,... in upload order = the order add_mesh_to_scene (scene.c:31) gave them. */
+int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris,
+                   const rt_flat_node* nodes, int32_t n_nodes,
+                   const uint8_t* h_rgba, int32_t tex_width, int32_t tex_height, int32_t* mesh_id);
+int rt_mesh_upload_tree(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const rt_tree_node* root,
+                        const uint8_t* h_rgba, int32_t tex_width, int32_t tex_height, int32_t* mesh_id);
+int rt_scene_clear(rt_ctx* ctx);                                  /* drops all meshes */
+int rt_mesh_count(const rt_ctx* ctx);
+
+/* ---- rendering ------------------------------------------------------------------------- */
+#define RT_FLAG_COUNT_WORK   0x1u   /* also count slab / triangle tests (slower; for measurement) */
+#define RT_FLAG_REFERENCE_ORDER 0x2u /* traverse every box the reference would, no distance culling */
+
+/* render_scene (scene.c:52-160) for one frame.  transforms[i] is scene->meshes[i].transform
+ * (set_mesh_position / set_mesh_rotation, mesh.c:121-127).  Output planes are device pointers:
+ *   d_rgb     width*height*3 bytes, row-major RGB8, index (y*width+x)*3      (scene.c:110) -- required
+ *   d_hit_id  width*height int32: (mesh_id<<24)|triangle index, -1 = miss   -- optional (NULL)
+ *   d_hit_t   width*height float: closest_t, 1e30f = miss                    -- optional
+ *   d_shadow  width*height uint8: 1 blocked, 0 lit, 255 = no primary hit     -- optional
+ * The launch is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the context's
+ * own stream).  Inputs are consumed before the call returns. */
+int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
+                    const rt_transform* transforms, int32_t n_transforms,
+                    int32_t width, int32_t height, uint32_t flags,
+                    void* d_rgb, void* d_hit_id, void* d_hit_t, void* d_shadow, void* stream);
+
+/* Same, for callers that hold host buffers (what scene->frames[current_frame] is in the
+ * reference): renders into context-owned device planes, waits, and copies back. */
+int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
+                         const rt_transform* transforms, int32_t n_transforms,
+                         int32_t width, int32_t height, uint32_t flags,
+                         uint8_t* h_rgb, int32_t* h_hit_id, float* h_hit_t, uint8_t* h_shadow);
+
+int rt_sync(rt_ctx* ctx, void* stream);                           /* waits for all launches on stream */
+/* GPU time of the most recent rt_render_frame launch, from HIP events recorded on its stream
+ * (waits for that launch). */
+int rt_last_kernel_ms(rt_ctx* ctx, float* ms);
+/* Counters of the most recent RT_FLAG_COUNT_WORK launch (waits for it). */
+int rt_last_counters(rt_ctx* ctx, rt_counters* out);
+
+/* Tunables, by name: "variant" (kernel variant id, 0 <= id < "n_variants"), "block" (threads per
+ * workgroup: 64, 128 or 256), "timing" (record HIP events around each launch, default 1).
+ * Read-only: "n_variants", "default_variant".  Unknown names give RT_ERR_INVALID. */
+int rt_set_option(rt_ctx* ctx, const char* name, int value);
+int rt_get_option(const rt_ctx* ctx, const char* name, int* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,226 @@
+"""ctypes binding of the C ABI in include/rt_mi355.h (raytracer_amd/csrc/librt_mi355.so).
+
+The library is the product: if it has not been built this module raises at import of the
+symbols, and every rendering call fails loudly when no GPU is present.  Nothing here falls
+back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librt_mi355.so")
+
+RT_OK = 0
+RT_ERR_INVALID, RT_ERR_DEVICE, RT_ERR_NO_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_CAPACITY = -1, -2, -3, -4, -5
+RT_FLAG_COUNT_WORK = 0x1
+RT_FLAG_REFERENCE_ORDER = 0x2
+RT_MAX_MESHES = 8
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Transform(C.Structure):
+    _fields_ = [("position", Vec3), ("rotation", Vec3)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", Vec3), ("look_at", Vec3), ("up", Vec3), ("fov", C.c_float)]
+
+
+class Light(C.Structure):
+    _fields_ = [("direction", Vec3), ("color", Vec3)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("primary_rays", "shadow_rays", "slab_tests", "tri_tests", "hit_pixels", "shadowed_pixels")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+TRI_FLOATS = 24          # rt_triangle: 96 bytes
+NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left", "<i4"), ("right", "<i4"),
+                       ("start", "<i4"), ("count", "<i4")])     # rt_flat_node: 40 bytes
+
+EXPORTS = [
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_bvh_build", "rt_bvh_flatten_tree",
+    "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
+    "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
+]
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, status: int, detail: str = ""):
+        self.status = status
+        super().__init__(f"rt_mi355 status {status} ({status_string(status)}){': ' + detail if detail else ''}")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make product` (hipcc, gfx950); "
+                               "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
+        L.rt_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.rt_ctx_destroy.argtypes = [vp]
+        L.rt_last_error.argtypes = [vp]
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_status_string.argtypes = [C.c_int]
+        L.rt_status_string.restype = C.c_char_p
+        L.rt_bvh_build.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+        L.rt_bvh_flatten_tree.argtypes = [vp, vp, i32, C.POINTER(i32)]
+        L.rt_mesh_upload.argtypes = [vp, vp, i32, vp, i32, vp, i32, i32, C.POINTER(i32)]
+        L.rt_mesh_upload_tree.argtypes = [vp, vp, i32, vp, vp, i32, i32, C.POINTER(i32)]
+        L.rt_scene_clear.argtypes = [vp]
+        L.rt_mesh_count.argtypes = [vp]
+        L.rt_render_frame.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, u32,
+                                      vp, vp, vp, vp, vp]
+        L.rt_render_frame_host.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, u32,
+                                           vp, vp, vp, vp]
+        L.rt_sync.argtypes = [vp, vp]
+        L.rt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.rt_last_counters.argtypes = [vp, C.POINTER(Counters)]
+        L.rt_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+        L.rt_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
+        for name in EXPORTS:
+            getattr(L, name)          # AttributeError here = the library does not export the ABI
+        _lib = L
+    return _lib
+
+
+def status_string(status: int) -> str:
+    return lib().rt_status_string(status).decode()
+
+
+def build_bvh(tris: np.ndarray):
+    """rt_bvh_build on a copy: returns (triangles in post-build order [n,24] f32, nodes NODE_DTYPE)."""
+    t = np.ascontiguousarray(tris, dtype=np.float32).copy()
+    n = int(t.shape[0])
+    nodes = np.zeros(max(2 * n, 1), dtype=NODE_DTYPE)
+    used = C.c_int32(0)
+    st = lib().rt_bvh_build(t.ctypes.data, n, nodes.ctypes.data, int(nodes.shape[0]), C.byref(used))
+    if st != RT_OK:
+        raise RtError(st)
+    return t, nodes[:used.value].copy()
+
+
+def _dev_ptr(x) -> Optional[int]:
+    """Device pointer of a torch tensor (or an int / None passed through)."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return int(x.data_ptr())
+
+
+class Context:
+    """One GPU rendering context (rt_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        st = lib().rt_ctx_create(int(device), C.byref(self._h))
+        if st != RT_OK:
+            self._h = C.c_void_p()
+            raise RtError(st, "rt_ctx_create")
+        self.device = int(device)
+
+    def _check(self, st: int):
+        if st != RT_OK:
+            raise RtError(st, lib().rt_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().rt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload_mesh(self, tris: np.ndarray, nodes: np.ndarray, rgba: np.ndarray) -> int:
+        tris = np.ascontiguousarray(tris, dtype=np.float32)
+        nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        assert tris.ndim == 2 and tris.shape[1] == TRI_FLOATS and rgba.ndim == 3 and rgba.shape[2] == 4
+        mid = C.c_int32(-1)
+        self._check(lib().rt_mesh_upload(self._h, tris.ctypes.data, int(tris.shape[0]), nodes.ctypes.data,
+                                         int(nodes.shape[0]), rgba.ctypes.data, int(rgba.shape[1]), int(rgba.shape[0]),
+                                         C.byref(mid)))
+        return mid.value
+
+    def upload_host_mesh(self, mesh) -> int:
+        """Uploads a Mesh struct of raytracer_amd.host_api (what create_mesh returns) as it stands."""
+        mid = C.c_int32(-1)
+        self._check(lib().rt_mesh_upload_tree(self._h, C.cast(mesh.triangles, C.c_void_p), int(mesh.triangle_count),
+                                              C.cast(mesh.bvh.root, C.c_void_p), C.cast(mesh.texture_data, C.c_void_p),
+                                              int(mesh.texture_width), int(mesh.texture_height), C.byref(mid)))
+        return mid.value
+
+    def clear_scene(self):
+        self._check(lib().rt_scene_clear(self._h))
+
+    def mesh_count(self) -> int:
+        return lib().rt_mesh_count(self._h)
+
+    def set_option(self, name: str, value: int):
+        self._check(lib().rt_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        self._check(lib().rt_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def render(self, camera: Camera, light: Light, transforms: Sequence[Transform], width: int, height: int,
+               rgb, hit_id=None, hit_t=None, shadow=None, flags: int = 0, stream: Optional[int] = None):
+        """Asynchronous launch into device buffers (torch tensors or raw device pointers)."""
+        arr = (Transform * len(transforms))(*transforms)
+        self._check(lib().rt_render_frame(self._h, C.byref(camera), C.byref(light), arr, len(transforms), int(width),
+                                          int(height), int(flags), _dev_ptr(rgb), _dev_ptr(hit_id), _dev_ptr(hit_t),
+                                          _dev_ptr(shadow), stream))
+
+    def render_host(self, camera: Camera, light: Light, transforms: Sequence[Transform], width: int, height: int,
+                    debug: bool = True, flags: int = 0):
+        """Synchronous render into fresh numpy arrays: (rgb[h,w,3], hit_id, hit_t, shadow)."""
+        arr = (Transform * len(transforms))(*transforms)
+        rgb = np.zeros((height, width, 3), np.uint8)
+        hid = np.zeros((height, width), np.int32) if debug else None
+        ht = np.zeros((height, width), np.float32) if debug else None
+        sh = np.zeros((height, width), np.uint8) if debug else None
+        self._check(lib().rt_render_frame_host(self._h, C.byref(camera), C.byref(light), arr, len(transforms), int(width),
+                                               int(height), int(flags), rgb.ctypes.data,
+                                               hid.ctypes.data if debug else None, ht.ctypes.data if debug else None,
+                                               sh.ctypes.data if debug else None))
+        return rgb, hid, ht, sh
+
+    def sync(self, stream: Optional[int] = None):
+        self._check(lib().rt_sync(self._h, stream))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0)
+        self._check(lib().rt_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def last_counters(self) -> dict:
+        c = Counters()
+        self._check(lib().rt_last_counters(self._h, C.byref(c)))
+        return c.as_dict()

@@ -1,0 +1,338 @@
+// rt_host.cpp -- the C ABI declared in include/rt_mi355.h: context, scene upload, per-frame
+// constant preparation and kernel launch.  There is no CPU rendering path in this library:
+// without a GPU every rendering entry point fails with RT_ERR_NO_DEVICE / RT_ERR_DEVICE.
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.h"
+#include "rt_pack.h"
+
+using namespace rt;
+
+namespace {
+
+struct DeviceMesh {
+    PairNode* d_pairs = nullptr;
+    TriRec* d_tris = nullptr;
+    AttrRec* d_attrs = nullptr;
+    uint32_t* d_texels = nullptr;
+    MeshArgs proto;          // static part filled at upload; placement filled per frame
+    int32_t n_tris = 0, n_pairs = 0;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool ev_pending = false;
+    std::vector<DeviceMesh> meshes;
+    DeviceCounters* d_counters = nullptr;
+    bool counters_pending = false;
+    // planes used by rt_render_frame_host
+    uint8_t* d_rgb = nullptr; int32_t* d_id = nullptr; float* d_t = nullptr; uint8_t* d_shadow = nullptr;
+    size_t plane_pixels = 0;
+    LaunchConfig cfg;
+    int timing = 1;
+    std::string err;
+};
+
+namespace {
+
+int fail(rt_ctx* ctx, int status, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return status;
+}
+
+int hip_fail(rt_ctx* ctx, hipError_t e, const char* what) {
+    std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();   // clear the sticky-less error slot
+    return fail(ctx, RT_ERR_DEVICE, msg);
+}
+
+#define RT_HIP(ctx, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+void free_mesh(DeviceMesh& m) {
+    if (m.d_pairs) (void)hipFree(m.d_pairs);
+    if (m.d_tris) (void)hipFree(m.d_tris);
+    if (m.d_attrs) (void)hipFree(m.d_attrs);
+    if (m.d_texels) (void)hipFree(m.d_texels);
+    m = DeviceMesh();
+}
+
+template <class T>
+int upload_array(rt_ctx* ctx, const std::vector<T>& src, T** dst) {
+    *dst = nullptr;
+    // Always allocate at least one record so kernels never see a null base.
+    const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    RT_HIP(ctx, hipMalloc((void**)dst, bytes));
+    if (!src.empty()) RT_HIP(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    else RT_HIP(ctx, hipMemset(*dst, 0, bytes));
+    return RT_OK;
+}
+
+int ensure_planes(rt_ctx* ctx, size_t pixels) {
+    if (pixels <= ctx->plane_pixels) return RT_OK;
+    if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+    if (ctx->d_id) (void)hipFree(ctx->d_id);
+    if (ctx->d_t) (void)hipFree(ctx->d_t);
+    if (ctx->d_shadow) (void)hipFree(ctx->d_shadow);
+    ctx->d_rgb = nullptr; ctx->d_id = nullptr; ctx->d_t = nullptr; ctx->d_shadow = nullptr;
+    ctx->plane_pixels = 0;
+    RT_HIP(ctx, hipMalloc((void**)&ctx->d_rgb, pixels * 3));
+    RT_HIP(ctx, hipMalloc((void**)&ctx->d_id, pixels * sizeof(int32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&ctx->d_t, pixels * sizeof(float)));
+    RT_HIP(ctx, hipMalloc((void**)&ctx->d_shadow, pixels));
+    ctx->plane_pixels = pixels;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_status_string(int status) {
+    switch (status) {
+        case RT_OK: return "ok";
+        case RT_ERR_INVALID: return "invalid argument";
+        case RT_ERR_DEVICE: return "device error";
+        case RT_ERR_NO_DEVICE: return "no usable GPU";
+        case RT_ERR_UNSUPPORTED: return "input outside the supported envelope";
+        case RT_ERR_CAPACITY: return "output array too small";
+        default: return "unknown status";
+    }
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rt_ctx_create(int device, rt_ctx** out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return RT_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n) return RT_ERR_NO_DEVICE;
+    rt_ctx* ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return RT_ERR_DEVICE;
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, sizeof(DeviceCounters));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rt_ctx_destroy(ctx);
+        return RT_ERR_DEVICE;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(rt_ctx* ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& m : ctx->meshes) free_mesh(m);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+    if (ctx->d_id) (void)hipFree(ctx->d_id);
+    if (ctx->d_t) (void)hipFree(ctx->d_t);
+    if (ctx->d_shadow) (void)hipFree(ctx->d_shadow);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int rt_bvh_build(rt_triangle* tris, int32_t n, rt_flat_node* nodes_out, int32_t cap, int32_t* n_nodes) {
+    if (n < 0 || (n > 0 && !tris) || !nodes_out || !n_nodes || cap < 1) return RT_ERR_INVALID;
+    BvhBuilder b(tris, nodes_out, cap);
+    if (b.build(0, n) < 0) return RT_ERR_CAPACITY;
+    *n_nodes = b.used();
+    return RT_OK;
+}
+
+int rt_bvh_flatten_tree(const rt_tree_node* root, rt_flat_node* nodes_out, int32_t cap, int32_t* n_nodes) {
+    if (!root || !nodes_out || !n_nodes || cap < 1) return RT_ERR_INVALID;
+    int32_t used = 0;
+    if (flatten_tree(root, nodes_out, cap, used, 0) < 0) return RT_ERR_CAPACITY;
+    *n_nodes = used;
+    return RT_OK;
+}
+
+int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes,
+                   const uint8_t* h_rgba, int32_t tex_width, int32_t tex_height, int32_t* mesh_id) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!h_rgba || tex_width <= 0 || tex_height <= 0) return fail(ctx, RT_ERR_INVALID, "texture missing or empty");
+    if ((int64_t)tex_width * tex_height > (int64_t)1 << 28) return fail(ctx, RT_ERR_UNSUPPORTED, "texture too large");
+    if ((int)ctx->meshes.size() >= kMaxMeshes) return fail(ctx, RT_ERR_UNSUPPORTED, "too many meshes in one scene");
+    PackedMesh pk;
+    std::string why;
+    int st = Packer(tris, n_tris, nodes, n_nodes, pk).run(why);
+    if (st != RT_OK) return fail(ctx, st, why);
+
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceMesh dm;
+    st = upload_array(ctx, pk.pairs, &dm.d_pairs);
+    if (st == RT_OK) st = upload_array(ctx, pk.tris, &dm.d_tris);
+    if (st == RT_OK) st = upload_array(ctx, pk.attrs, &dm.d_attrs);
+    if (st == RT_OK) {
+        const size_t bytes = (size_t)tex_width * (size_t)tex_height * 4;
+        hipError_t e = hipMalloc((void**)&dm.d_texels, bytes);
+        if (e == hipSuccess) e = hipMemcpy(dm.d_texels, h_rgba, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) st = hip_fail(ctx, e, "texture upload");
+    }
+    if (st != RT_OK) { free_mesh(dm); return st; }
+    memset(&dm.proto, 0, sizeof(dm.proto));
+    dm.proto.pairs = dm.d_pairs; dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs; dm.proto.texels = dm.d_texels;
+    memcpy(dm.proto.root_min, pk.root_min, 12);
+    memcpy(dm.proto.root_max, pk.root_max, 12);
+    dm.proto.root_ref = pk.root_ref;
+    dm.proto.tex_w = tex_width; dm.proto.tex_h = tex_height;
+    dm.proto.empty = pk.empty ? 1u : 0u;
+    dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.pairs.size();
+    ctx->meshes.push_back(dm);
+    if (mesh_id) *mesh_id = (int32_t)ctx->meshes.size() - 1;
+    return RT_OK;
+}
+
+int rt_mesh_upload_tree(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const rt_tree_node* root,
+                        const uint8_t* h_rgba, int32_t tex_width, int32_t tex_height, int32_t* mesh_id) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!root) return fail(ctx, RT_ERR_INVALID, "null BVH root");
+    std::vector<rt_flat_node> flat((size_t)(n_tris > 0 ? 2 * (size_t)n_tris : 1) + 1);
+    int32_t used = 0;
+    if (flatten_tree(root, flat.data(), (int32_t)flat.size(), used, 0) < 0) return fail(ctx, RT_ERR_UNSUPPORTED, "BVH has more nodes than 2*triangles+1");
+    return rt_mesh_upload(ctx, tris, n_tris, flat.data(), used, h_rgba, tex_width, tex_height, mesh_id);
+}
+
+int rt_scene_clear(rt_ctx* ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& m : ctx->meshes) free_mesh(m);
+    ctx->meshes.clear();
+    return RT_OK;
+}
+
+int rt_mesh_count(const rt_ctx* ctx) { return ctx ? (int)ctx->meshes.size() : RT_ERR_INVALID; }
+
+int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
+                    int32_t n_transforms, int32_t width, int32_t height, uint32_t flags, void* d_rgb, void* d_hit_id,
+                    void* d_hit_t, void* d_shadow, void* stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!camera || !light || !d_rgb) return fail(ctx, RT_ERR_INVALID, "camera, light and d_rgb are required");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    if (n_transforms != (int32_t)ctx->meshes.size() || (n_transforms > 0 && !transforms))
+        return fail(ctx, RT_ERR_INVALID, "one transform per uploaded mesh is required");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+
+    FrameArgs A;
+    memset(&A, 0, sizeof(A));
+    fill_camera(*camera, *light, width, height, A);
+    A.n_mesh = n_transforms;
+    A.flags = flags;
+    for (int32_t m = 0; m < n_transforms; m++) {
+        A.mesh[m] = ctx->meshes[(size_t)m].proto;
+        fill_placement(transforms[m], A, A.mesh[m]);
+    }
+    OutputPlanes O;
+    O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_id; O.hit_t = (float*)d_hit_t; O.shadow = (uint8_t*)d_shadow;
+    O.counters = ctx->d_counters;
+    if (flags & RT_FLAG_COUNT_WORK) {
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DeviceCounters), s));
+        ctx->counters_pending = true;
+    }
+    if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
+    RT_HIP(ctx, launch_render(A, O, ctx->cfg, s));
+    if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
+    return RT_OK;
+}
+
+int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
+                         int32_t n_transforms, int32_t width, int32_t height, uint32_t flags, uint8_t* h_rgb,
+                         int32_t* h_hit_id, float* h_hit_t, uint8_t* h_shadow) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!h_rgb) return fail(ctx, RT_ERR_INVALID, "h_rgb is required");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t pixels = (size_t)width * (size_t)height;
+    int st = ensure_planes(ctx, pixels);
+    if (st != RT_OK) return st;
+    st = rt_render_frame(ctx, camera, light, transforms, n_transforms, width, height, flags, ctx->d_rgb,
+                         h_hit_id ? ctx->d_id : nullptr, h_hit_t ? ctx->d_t : nullptr, h_shadow ? ctx->d_shadow : nullptr, nullptr);
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(h_rgb, ctx->d_rgb, pixels * 3, hipMemcpyDeviceToHost));
+    if (h_hit_id) RT_HIP(ctx, hipMemcpy(h_hit_id, ctx->d_id, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (h_hit_t) RT_HIP(ctx, hipMemcpy(h_hit_t, ctx->d_t, pixels * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_shadow) RT_HIP(ctx, hipMemcpy(h_shadow, ctx->d_shadow, pixels, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx* ctx, void* stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    return RT_OK;
+}
+
+int rt_last_kernel_ms(rt_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return RT_ERR_INVALID;
+    if (!ctx->ev_pending) return fail(ctx, RT_ERR_INVALID, "no timed launch yet (option \"timing\" off?)");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+    RT_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end));
+    return RT_OK;
+}
+
+int rt_last_counters(rt_ctx* ctx, rt_counters* out) {
+    if (!ctx || !out) return RT_ERR_INVALID;
+    if (!ctx->counters_pending) return fail(ctx, RT_ERR_INVALID, "no RT_FLAG_COUNT_WORK launch yet");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipDeviceSynchronize());
+    DeviceCounters c;
+    RT_HIP(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    out->primary_rays = c.primary_rays; out->shadow_rays = c.shadow_rays;
+    out->slab_tests = c.slab_tests; out->tri_tests = c.tri_tests;
+    out->hit_pixels = c.hit_pixels; out->shadowed_pixels = c.shadowed_pixels;
+    return RT_OK;
+}
+
+int rt_set_option(rt_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return RT_ERR_INVALID;
+    if (!strcmp(name, "variant")) {
+        if (value < 0 || value >= kNumVariants) return fail(ctx, RT_ERR_INVALID, "unknown kernel variant");
+        ctx->cfg.variant = value; return RT_OK;
+    }
+    if (!strcmp(name, "block")) {
+        if (value != 64 && value != 128 && value != 256) return fail(ctx, RT_ERR_INVALID, "block must be 64, 128 or 256");
+        ctx->cfg.block = value; return RT_OK;
+    }
+    if (!strcmp(name, "timing")) { ctx->timing = value ? 1 : 0; return RT_OK; }
+    return fail(ctx, RT_ERR_INVALID, std::string("unknown option ") + name);
+}
+
+int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
+    if (!ctx || !name || !value) return RT_ERR_INVALID;
+    if (!strcmp(name, "variant")) { *value = ctx->cfg.variant; return RT_OK; }
+    if (!strcmp(name, "block")) { *value = ctx->cfg.block; return RT_OK; }
+    if (!strcmp(name, "timing")) { *value = ctx->timing; return RT_OK; }
+    if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }
+    if (!strcmp(name, "default_variant")) { *value = kDefaultVariant; return RT_OK; }
+    return RT_ERR_INVALID;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// rt_layout.h -- data layouts shared by the host packer and the HIP kernels.
+//
+// HBM layout of a mesh (all arrays 64-byte aligned, one allocation each per mesh):
+//   PairNode[]  one 64-byte record per INTERNAL node of the reference BVH: the boxes of both
+//               children plus a reference to each.  Visiting an internal node therefore costs one
+//               aligned 64-byte fetch and yields both child slab tests; the node's own box was
+//               tested when its parent was visited (the root box sits in MeshArgs).
+//   TriRec[]    48 bytes per triangle, post-build order: v0, e1 = v1-v0, e2 = v2-v0 (the two
+//               subtractions Moeller-Trumbore starts with, done once on the host, same rounding)
+//               and the triangle's tie priority.
+//   AttrRec[]   64 bytes per triangle: texture coordinates and vertex normals, read once per hit.
+//   texture     RGBA8 rows exactly as decoded.
+#pragma once
+#include <stdint.h>
+
+namespace rt {
+
+constexpr int kMaxMeshes = 8;
+constexpr int kStackDepth = 32;            // entries per lane; covers trees up to depth 30
+
+// Child / stack reference.  bit31 set: leaf, bits 30..24 = triangle count (1..127),
+// bits 23..0 = first triangle.  bit31 clear: index of a PairNode.
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr int kMaxLeafTris = 127;
+inline constexpr uint32_t leaf_ref(uint32_t start, uint32_t count) { return kLeafBit | (count << 24) | start; }
+
+struct alignas(64) PairNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    uint32_t lref, rref;
+    uint32_t pad[2];
+};
+static_assert(sizeof(PairNode) == 64, "PairNode must be one 64-byte record");
+
+struct alignas(16) TriRec {
+    float v0[3];
+    uint32_t prio;        // winner among equal-t hits = highest prio (see host packer)
+    float e1[3];
+    float pad1;
+    float e2[3];
+    float pad2;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec is three float4");
+
+struct alignas(64) AttrRec {
+    float t0[2], t1[2], t2[2];
+    float n0[3], n1[3], n2[3];
+    float pad;
+};
+static_assert(sizeof(AttrRec) == 64, "AttrRec must be one 64-byte record");
+
+// Per-mesh kernel arguments: static geometry handles + the per-frame constants that the
+// reference re-derives for every ray (ray.c:5-16, 27-37), computed once per frame on the host
+// with the same float operations.
+struct MeshArgs {
+    const PairNode* pairs;
+    const TriRec* tris;
+    const AttrRec* attrs;
+    const uint32_t* texels;      // RGBA8 packed little-endian: R in bits 0..7
+    float root_min[3], root_max[3];
+    uint32_t root_ref;           // leaf_ref(...) or PairNode index 0
+    int32_t tex_w, tex_h;
+    uint32_t empty;              // 1: mesh has no triangles (root box never leads to a hit)
+    float inv[3][4];             // rows 0..2 of inverse(T*Rz*Ry*Rx)
+    float wrow[4];               // row 3 of the same matrix (mat4_transform_point divides by it)
+    float nrm[3][3];             // upper 3x3 of transpose(inverse(Rz*Ry*Rx))
+    float cam_o[3];              // camera position in mesh space (mat4_transform_point, hoisted)
+    float lit_d[3];              // normalised light direction in mesh space
+    float lit_inv[3];            // 1.0f / lit_d
+    uint32_t w_mode;             // 0: general w; 1: w == wrow[3] for every finite point; 2: w == 1.0f
+    uint32_t pad;
+};
+
+struct FrameArgs {
+    int32_t width, height;
+    int32_t n_mesh;
+    uint32_t flags;
+    float cam_pos[3];
+    float cam_right[3], cam_up[3], cam_fwd[3];
+    float aspect, scale;
+    float light_dir[3], light_color[3];
+    MeshArgs mesh[kMaxMeshes];
+};
+
+struct DeviceCounters {          // accumulated with atomics when counting is requested
+    unsigned long long primary_rays, shadow_rays, slab_tests, tri_tests, hit_pixels, shadowed_pixels;
+};
+
+struct OutputPlanes {
+    uint8_t* rgb;
+    int32_t* hit_id;
+    float* hit_t;
+    uint8_t* shadow;
+    DeviceCounters* counters;
+};
+
+}  // namespace rt

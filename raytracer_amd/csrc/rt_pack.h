@@ -1,0 +1,265 @@
+// rt_pack.h -- host-side scene preparation: the reference BVH builder, tree flattening, the
+// packer that turns (triangles, flat nodes) into the kernel layout of rt_layout.h, and the
+// per-frame constants.  Pure host C++ (no HIP calls), shared by the product library and by the
+// host build of the pixel pipeline that the CPU tests use.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355.h"
+#include "rt_exact.h"
+#include "rt_layout.h"
+
+namespace rt {
+
+static_assert(sizeof(rt_triangle) == 96, "reference Triangle is 96 bytes");
+static_assert(sizeof(rt_flat_node) == 40, "flat node is 40 bytes");
+static_assert(sizeof(rt_transform) == 24 && sizeof(rt_camera) == 40 && sizeof(rt_light) == 24, "reference struct sizes");
+
+inline F3 f3(const rt_vec3& v) { return f3(v.x, v.y, v.z); }
+
+// ------------------------------------------------------------------------------------------
+// Reference builder (accel/bvh.c:4-59).  The tree is produced in creation order
+// (node, left subtree, right subtree) and the triangle array is permuted in place.
+// ------------------------------------------------------------------------------------------
+class BvhBuilder {
+public:
+    BvhBuilder(rt_triangle* tris, rt_flat_node* out, int32_t cap) : tris_(tris), out_(out), cap_(cap) {}
+    // Returns node index or -1 when out of space.
+    int32_t build(int32_t start, int32_t count) {
+        if (used_ >= cap_) return -1;
+        const int32_t me = used_++;
+        rt_flat_node& n = out_[me];
+        n.start_idx = start; n.triangle_count = count; n.left = n.right = -1;
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};       // aabb.c:3-8
+        for (int32_t i = 0; i < count; i++) {
+            const rt_vec3* corner = &tris_[start + i].v0;                             // v0, v1, v2 are contiguous
+            for (int c = 0; c < 3; c++) {                                             // aabb.c:10-23
+                lo[0] = fminf(lo[0], corner[c].x); lo[1] = fminf(lo[1], corner[c].y); lo[2] = fminf(lo[2], corner[c].z);
+                hi[0] = fmaxf(hi[0], corner[c].x); hi[1] = fmaxf(hi[1], corner[c].y); hi[2] = fmaxf(hi[2], corner[c].z);
+            }
+        }
+        n.bounds_min = {lo[0], lo[1], lo[2]};
+        n.bounds_max = {hi[0], hi[1], hi[2]};
+        if (count <= 4) return me;                                                    // bvh.c:19
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        int axis = 0;
+        if (ey > ex) axis = 1;                                                        // bvh.c:23
+        if (ez > ex && ez > ey) axis = 2;                                             // bvh.c:24 (compares with ex, not the running max)
+        float split = 0.0f;
+        for (int32_t i = 0; i < count; i++) split += key(tris_[start + i], axis);     // bvh.c:28-32
+        split /= (float)count;                                                        // bvh.c:33
+        int32_t mid = start;
+        for (int32_t i = 0; i < count; i++) {                                         // bvh.c:37-48
+            if (key(tris_[start + i], axis) < split) {
+                rt_triangle tmp = tris_[start + i];
+                tris_[start + i] = tris_[mid];
+                tris_[mid] = tmp;
+                mid++;
+            }
+        }
+        const int32_t nl = mid - start;
+        if (nl > 0 && nl < count) {                                                   // bvh.c:52-55
+            const int32_t l = build(start, nl);
+            if (l < 0) return -1;
+            const int32_t r = build(mid, count - nl);
+            if (r < 0) return -1;
+            out_[me].left = l; out_[me].right = r;
+        }
+        return me;
+    }
+    int32_t used() const { return used_; }
+
+private:
+    // bvh.c:30-31: one coordinate of ((v0+v1)+v2) * (1.0f/3.0f)
+    static float key(const rt_triangle& t, int axis) {
+        const float third = 1.0f / 3.0f;
+        const float a = axis == 0 ? t.v0.x : (axis == 1 ? t.v0.y : t.v0.z);
+        const float b = axis == 0 ? t.v1.x : (axis == 1 ? t.v1.y : t.v1.z);
+        const float c = axis == 0 ? t.v2.x : (axis == 1 ? t.v2.y : t.v2.z);
+        return ((a + b) + c) * third;
+    }
+    rt_triangle* tris_;
+    rt_flat_node* out_;
+    int32_t cap_;
+    int32_t used_ = 0;
+};
+
+inline int32_t flatten_tree(const rt_tree_node* n, rt_flat_node* out, int32_t cap, int32_t& used, int depth) {
+    if (used >= cap || depth > 4096) return -1;
+    const int32_t me = used++;
+    out[me].bounds_min = n->bounds_min; out[me].bounds_max = n->bounds_max;
+    out[me].start_idx = n->start_idx; out[me].triangle_count = n->triangle_count;
+    out[me].left = out[me].right = -1;
+    if (n->left) { const int32_t l = flatten_tree(n->left, out, cap, used, depth + 1); if (l < 0) return -1; out[me].left = l; }
+    if (n->right) { const int32_t r = flatten_tree(n->right, out, cap, used, depth + 1); if (r < 0) return -1; out[me].right = r; }
+    return me;
+}
+
+// ------------------------------------------------------------------------------------------
+// Packer.
+// ------------------------------------------------------------------------------------------
+struct PackedMesh {
+    std::vector<PairNode> pairs;
+    std::vector<TriRec> tris;
+    std::vector<AttrRec> attrs;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    uint32_t root_ref = kLeafBit;     // empty leaf
+    bool empty = true;
+    int depth = 0;                    // deepest chain of PairNodes from the root
+};
+
+class Packer {
+public:
+    Packer(const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes, PackedMesh& out)
+        : tris_(tris), n_tris_(n_tris), nodes_(nodes), n_nodes_(n_nodes), out_(out) {}
+
+    // Returns RT_OK or an rt_status; err gets the reason.
+    int run(std::string& err) {
+        out_ = PackedMesh();
+        if (n_tris_ < 0 || n_nodes_ < 0 || (n_tris_ > 0 && !tris_) || (n_nodes_ > 0 && !nodes_)) { err = "null or negative mesh arrays"; return RT_ERR_INVALID; }
+        if (n_tris_ > RT_MAX_MESH_TRIS) { err = "too many triangles in one mesh"; return RT_ERR_UNSUPPORTED; }
+        out_.tris.resize((size_t)n_tris_);
+        out_.attrs.resize((size_t)n_tris_);
+        for (int32_t i = 0; i < n_tris_; i++) {
+            const rt_triangle& s = tris_[i];
+            TriRec& t = out_.tris[(size_t)i];
+            const F3 v0 = f3(s.v0), e1 = sub(f3(s.v1), v0), e2 = sub(f3(s.v2), v0);   // ray.c:45-46
+            t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z; t.prio = 0;
+            t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z; t.pad1 = 0;
+            t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z; t.pad2 = 0;
+            AttrRec& a = out_.attrs[(size_t)i];
+            a.t0[0] = s.t0.u; a.t0[1] = s.t0.v; a.t1[0] = s.t1.u; a.t1[1] = s.t1.v; a.t2[0] = s.t2.u; a.t2[1] = s.t2.v;
+            a.n0[0] = s.n0.x; a.n0[1] = s.n0.y; a.n0[2] = s.n0.z;
+            a.n1[0] = s.n1.x; a.n1[1] = s.n1.y; a.n1[2] = s.n1.z;
+            a.n2[0] = s.n2.x; a.n2[1] = s.n2.y; a.n2[2] = s.n2.z;
+            a.pad = 0;
+        }
+        if (n_nodes_ == 0) return RT_OK;                         // nothing to traverse
+        covered_.assign((size_t)n_tris_, 0);
+        visited_.assign((size_t)n_nodes_, 0);
+        const rt_flat_node& root = nodes_[0];
+        memcpy(out_.root_min, &root.bounds_min, 12);
+        memcpy(out_.root_max, &root.bounds_max, 12);
+        uint32_t ref = 0;
+        const int st = emit(0, 0, ref, err);
+        if (st != RT_OK) return st;
+        out_.root_ref = ref;
+        out_.empty = false;
+        if (out_.depth + 2 > kStackDepth || out_.depth > RT_MAX_TREE_DEPTH) { err = "BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
+        return RT_OK;
+    }
+
+private:
+    int emit(int32_t ni, int depth, uint32_t& ref, std::string& err) {
+        if (ni < 0 || ni >= n_nodes_) { err = "node index out of range"; return RT_ERR_INVALID; }
+        if (visited_[(size_t)ni]) { err = "node reachable twice (not a tree)"; return RT_ERR_INVALID; }
+        visited_[(size_t)ni] = 1;
+        if (depth > RT_MAX_TREE_DEPTH + 8) { err = "BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
+        const rt_flat_node& n = nodes_[ni];
+        if (n.left < 0 && n.right < 0) {
+            const int64_t s = n.start_idx, c = n.triangle_count;
+            if (s < 0 || c < 0 || s + c > n_tris_) { err = "leaf triangle range out of bounds"; return RT_ERR_INVALID; }
+            for (int64_t i = c - 1; i >= 0; i--) {                // later leaf > earlier leaf; inside a leaf lower index > higher
+                if (covered_[(size_t)(s + i)]) { err = "triangle referenced by two leaves"; return RT_ERR_INVALID; }
+                covered_[(size_t)(s + i)] = 1;
+                out_.tris[(size_t)(s + i)].prio = ++next_prio_;
+            }
+            return emit_leaf((uint32_t)s, (uint32_t)c, n, depth, ref, err);
+        }
+        if (n.left < 0 || n.right < 0) { err = "internal node with a single child"; return RT_ERR_UNSUPPORTED; }
+        if (out_.pairs.size() >= (size_t)kLeafBit) { err = "too many internal nodes"; return RT_ERR_UNSUPPORTED; }
+        const uint32_t me = (uint32_t)out_.pairs.size();
+        out_.pairs.emplace_back();
+        if (depth + 1 > out_.depth) out_.depth = depth + 1;
+        uint32_t l = 0, r = 0;
+        int st = emit(n.left, depth + 1, l, err);
+        if (st != RT_OK) return st;
+        st = emit(n.right, depth + 1, r, err);
+        if (st != RT_OK) return st;
+        PairNode& p = out_.pairs[me];
+        memcpy(p.lmin, &nodes_[n.left].bounds_min, 12);  memcpy(p.lmax, &nodes_[n.left].bounds_max, 12);
+        memcpy(p.rmin, &nodes_[n.right].bounds_min, 12); memcpy(p.rmax, &nodes_[n.right].bounds_max, 12);
+        p.lref = l; p.rref = r; p.pad[0] = p.pad[1] = 0;
+        ref = me;
+        return RT_OK;
+    }
+    // A leaf of up to kMaxLeafTris triangles is one reference.  A larger one (the reference makes
+    // them when a split leaves one side empty) becomes a chain of PairNodes whose two boxes both
+    // repeat the leaf's own box: the slab test on them repeats the test that already passed, so
+    // the set of triangles tested, and the result, are unchanged.
+    int emit_leaf(uint32_t start, uint32_t count, const rt_flat_node& box, int depth, uint32_t& ref, std::string& err) {
+        if (count <= (uint32_t)kMaxLeafTris) { ref = leaf_ref(start, count); return RT_OK; }
+        if (depth > RT_MAX_TREE_DEPTH + 8) { err = "oversize leaf too deep"; return RT_ERR_UNSUPPORTED; }
+        const uint32_t me = (uint32_t)out_.pairs.size();
+        out_.pairs.emplace_back();
+        if (depth + 1 > out_.depth) out_.depth = depth + 1;
+        const uint32_t half = count / 2;
+        uint32_t l = 0, r = 0;
+        int st = emit_leaf(start, half, box, depth + 1, l, err);
+        if (st != RT_OK) return st;
+        st = emit_leaf(start + half, count - half, box, depth + 1, r, err);
+        if (st != RT_OK) return st;
+        PairNode& p = out_.pairs[me];
+        memcpy(p.lmin, &box.bounds_min, 12); memcpy(p.lmax, &box.bounds_max, 12);
+        memcpy(p.rmin, &box.bounds_min, 12); memcpy(p.rmax, &box.bounds_max, 12);
+        p.lref = l; p.rref = r; p.pad[0] = p.pad[1] = 0;
+        ref = me;
+        return RT_OK;
+    }
+
+    const rt_triangle* tris_;
+    int32_t n_tris_;
+    const rt_flat_node* nodes_;
+    int32_t n_nodes_;
+    PackedMesh& out_;
+    std::vector<uint8_t> covered_, visited_;
+    uint32_t next_prio_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// Per-frame constants.
+// ------------------------------------------------------------------------------------------
+// Camera part of FrameArgs (camera.c:13-17 runs these per ray; they depend on the camera only).
+inline void fill_camera(const rt_camera& cam, const rt_light& light, int32_t width, int32_t height, FrameArgs& A) {
+    const F3 fwd = unit(sub(f3(cam.look_at), f3(cam.position)));
+    const F3 right = unit(cross(fwd, f3(cam.up)));
+    const F3 up = cross(right, fwd);
+    A.width = width; A.height = height;
+    A.cam_pos[0] = cam.position.x; A.cam_pos[1] = cam.position.y; A.cam_pos[2] = cam.position.z;
+    A.cam_right[0] = right.x; A.cam_right[1] = right.y; A.cam_right[2] = right.z;
+    A.cam_up[0] = up.x; A.cam_up[1] = up.y; A.cam_up[2] = up.z;
+    A.cam_fwd[0] = fwd.x; A.cam_fwd[1] = fwd.y; A.cam_fwd[2] = fwd.z;
+    A.aspect = (float)width / (float)height;                                        // scene.c:53
+    // camera.c:17: (fov*0.5f) in float, then * M_PI / 180.0f in double, narrowed for tanf.
+    A.scale = tanf((float)((double)(cam.fov * 0.5f) * 3.14159265358979323846 / (double)180.0f));
+    A.light_dir[0] = light.direction.x; A.light_dir[1] = light.direction.y; A.light_dir[2] = light.direction.z;
+    A.light_color[0] = light.color.x; A.light_color[1] = light.color.y; A.light_color[2] = light.color.z;
+}
+
+// Placement part of one MeshArgs (ray.c:5-16 and ray.c:27-37 run these per ray).
+inline void fill_placement(const rt_transform& tf, const FrameArgs& A, MeshArgs& M) {
+    const M4 rot = m4_mul(m4_rotation(2, tf.rotation.z), m4_mul(m4_rotation(1, tf.rotation.y), m4_rotation(0, tf.rotation.x)));
+    const M4 inv = m4_inverse(m4_mul(m4_translation(f3(tf.position)), rot));
+    const M4 nrm = m4_transpose(m4_inverse(rot));
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) M.inv[i][j] = inv.m[i][j];
+    for (int j = 0; j < 4; j++) M.wrow[j] = inv.m[3][j];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M.nrm[i][j] = nrm.m[i][j];
+    const F3 co = xform_point(M.inv, M.wrow, f3(A.cam_pos));
+    M.cam_o[0] = co.x; M.cam_o[1] = co.y; M.cam_o[2] = co.z;
+    const F3 ld = unit(xform_vector<4>(M.inv, f3(A.light_dir)));
+    const F3 li = recip(ld);
+    M.lit_d[0] = ld.x; M.lit_d[1] = ld.y; M.lit_d[2] = ld.z;
+    M.lit_inv[0] = li.x; M.lit_inv[1] = li.y; M.lit_inv[2] = li.z;
+    // With a bottom row of (+-0, +-0, +-0, w33), w33 != 0, the w of mat4_transform_point equals
+    // w33 exactly for every finite point.
+    M.w_mode = 0;
+    if (M.wrow[0] == 0.0f && M.wrow[1] == 0.0f && M.wrow[2] == 0.0f && M.wrow[3] != 0.0f) M.w_mode = (M.wrow[3] == 1.0f) ? 2u : 1u;
+    M.pad = 0;
+}
+
+}  // namespace rt

@@ -1,0 +1,382 @@
+// raytracer_host.cpp -- the reference's host API over the MI355X rendering core.
+//
+// Scene bookkeeping, OBJ/WebP loading and the BVH build stay on the host (they run once at
+// load time in the reference too); render_scene() hands the frame to librt_mi355.so.
+#include "raytracer_host.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355.h"
+#include "../csrc/rt_exact.h"
+#include "../csrc/rt_pack.h"
+
+static_assert(sizeof(Triangle) == sizeof(rt_triangle) && sizeof(Transform) == sizeof(rt_transform), "layout");
+static_assert(sizeof(Camera) == sizeof(rt_camera) && sizeof(DirectionalLight) == sizeof(rt_light), "layout");
+static_assert(sizeof(BVHNode) == sizeof(rt_tree_node) && sizeof(BVHNode) == 48, "layout");
+
+namespace {
+
+// ------------------------------------------------------------------ device side-table
+// The reference's Scene has no room for a device handle and is passed around by value, so the
+// GPU context lives in a table keyed by the scene's frame-pointer array (unique while alive).
+struct MeshKey {
+    const void* tris; const void* tex; const void* root; size_t n; int tw, th;
+    bool operator==(const MeshKey& o) const {
+        return tris == o.tris && tex == o.tex && root == o.root && n == o.n && tw == o.tw && th == o.th;
+    }
+};
+struct SceneState {
+    rt_ctx* ctx = nullptr;
+    std::vector<MeshKey> uploaded;
+    int last_status = 0;
+};
+std::mutex g_lock;
+std::map<const void*, SceneState> g_states;
+int g_device = -1;
+
+int pick_device() {
+    if (g_device >= 0) return g_device;
+    const char* e = getenv("RT_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+SceneState* state_of(const Scene* scene, bool create) {
+    auto it = g_states.find((const void*)scene->frames);
+    if (it != g_states.end()) return &it->second;
+    if (!create) return nullptr;
+    return &g_states[(const void*)scene->frames];
+}
+
+int sync_scene(Scene* scene, SceneState& st) {
+    if (!st.ctx) {
+        int rc = rt_ctx_create(pick_device(), &st.ctx);
+        if (rc != RT_OK) { fprintf(stderr, "render_scene: cannot open GPU %d: %s\n", pick_device(), rt_status_string(rc)); return rc; }
+    }
+    std::vector<MeshKey> now;
+    for (size_t i = 0; i < scene->mesh_count; i++) {
+        const Mesh& m = scene->meshes[i];
+        now.push_back(MeshKey{m.triangles, m.texture_data, m.bvh.root, m.triangle_count, m.texture_width, m.texture_height});
+    }
+    if (now == st.uploaded) return RT_OK;
+    int rc = rt_scene_clear(st.ctx);
+    st.uploaded.clear();
+    for (size_t i = 0; rc == RT_OK && i < scene->mesh_count; i++) {
+        const Mesh& m = scene->meshes[i];
+        if (!m.bvh.root || !m.texture_data) { fprintf(stderr, "render_scene: mesh %zu was not loaded\n", i); return RT_ERR_INVALID; }
+        rc = rt_mesh_upload_tree(st.ctx, (const rt_triangle*)m.triangles, (int32_t)m.triangle_count,
+                                 (const rt_tree_node*)m.bvh.root, m.texture_data, m.texture_width, m.texture_height, nullptr);
+    }
+    if (rc != RT_OK) { fprintf(stderr, "render_scene: scene upload failed: %s (%s)\n", rt_status_string(rc), rt_last_error(st.ctx)); return rc; }
+    st.uploaded = now;
+    return RT_OK;
+}
+
+int render_into(Scene* scene, uint8_t* rgb, int32_t* hit_id, float* hit_t, uint8_t* shadow) {
+    std::lock_guard<std::mutex> g(g_lock);
+    SceneState* st = state_of(scene, true);
+    int rc = sync_scene(scene, *st);
+    if (rc == RT_OK) {
+        std::vector<rt_transform> tfs(scene->mesh_count);
+        for (size_t i = 0; i < scene->mesh_count; i++) memcpy(&tfs[i], &scene->meshes[i].transform, sizeof(rt_transform));
+        rc = rt_render_frame_host(st->ctx, (const rt_camera*)&scene->camera, (const rt_light*)&scene->light, tfs.data(),
+                                  (int32_t)tfs.size(), scene->width, scene->height, 0, rgb, hit_id, hit_t, shadow);
+        if (rc != RT_OK) fprintf(stderr, "render_scene: %s (%s)\n", rt_status_string(rc), rt_last_error(st->ctx));
+    }
+    st->last_status = rc;
+    return rc;
+}
+
+// ------------------------------------------------------------------ libwebp at run time
+// The image ships libwebp.so.7 but no headers; only the two decode entry points the reference
+// uses (mesh.c:105,131) are needed, so they are looked up by name.
+typedef uint8_t* (*webp_decode_fn)(const uint8_t*, size_t, int*, int*);
+typedef void (*webp_free_fn)(void*);
+webp_decode_fn g_webp_decode = nullptr;
+webp_free_fn g_webp_free = nullptr;
+
+bool load_webp() {
+    if (g_webp_decode) return true;
+    static const char* names[] = {"libwebp.so.7", "libwebp.so", "libwebp.so.6", nullptr};
+    for (int i = 0; names[i]; i++) {
+        void* h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_webp_decode = (webp_decode_fn)dlsym(h, "WebPDecodeRGBA");
+        g_webp_free = (webp_free_fn)dlsym(h, "WebPFree");
+        if (g_webp_decode) return true;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ OBJ reading
+// Same grammar the reference accepts (mesh.c:41-76): "v x y z", "vt u v", "vn x y z" and
+// "f a/b/c a/b/c a/b/c" with 1-based indices; everything else is skipped.  Storage grows as
+// needed instead of the reference's fixed million-element arrays.
+const char* skip_ws(const char* p) { while (*p == ' ' || *p == '\t') p++; return p; }
+
+int read_floats(const char* p, float* out, int n) {
+    int got = 0;
+    for (; got < n; got++) {
+        char* end = nullptr;
+        float v = strtof(p, &end);
+        if (end == p) break;
+        out[got] = v; p = end;
+    }
+    return got;
+}
+
+bool read_corner(const char*& p, long idx[3]) {
+    for (int k = 0; k < 3; k++) {
+        char* end = nullptr;
+        idx[k] = strtol(p, &end, 10);
+        if (end == p) return false;
+        p = end;
+        if (k < 2) { if (*p != '/') return false; p++; }
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ small constructors
+Camera create_camera(Vec3 position, Vec3 look_at, Vec3 up, float fov) {            // camera.c:8-10
+    Camera c; c.position = position; c.look_at = look_at; c.up = up; c.fov = fov; return c;
+}
+
+DirectionalLight create_directional_light(Vec3 direction, Vec3 color) {            // light.c:3-5
+    const rt::F3 d = rt::unit(rt::f3(direction.x, direction.y, direction.z));
+    DirectionalLight l; l.direction = Vec3{d.x, d.y, d.z}; l.color = color; return l;
+}
+
+// ------------------------------------------------------------------ BVH (host build)
+BVHNode* create_bvh_node(Triangle* triangles, int start, int count) {              // bvh.c:4-59
+    if (count < 0) return nullptr;
+    std::vector<rt_flat_node> flat((size_t)2 * (size_t)(count > 0 ? count : 1) + 1);
+    rt::BvhBuilder b((rt_triangle*)triangles, flat.data(), (int32_t)flat.size());
+    if (b.build(start, count) < 0) return nullptr;
+    std::vector<BVHNode*> heap((size_t)b.used(), nullptr);
+    for (int32_t i = b.used() - 1; i >= 0; i--) {            // children have larger indices than their parent
+        BVHNode* n = (BVHNode*)malloc(sizeof(BVHNode));
+        if (!n) return nullptr;
+        memcpy(&n->bounds.min, &flat[(size_t)i].bounds_min, 12);
+        memcpy(&n->bounds.max, &flat[(size_t)i].bounds_max, 12);
+        n->start_idx = flat[(size_t)i].start_idx; n->triangle_count = flat[(size_t)i].triangle_count;
+        n->left = flat[(size_t)i].left >= 0 ? heap[(size_t)flat[(size_t)i].left] : nullptr;
+        n->right = flat[(size_t)i].right >= 0 ? heap[(size_t)flat[(size_t)i].right] : nullptr;
+        heap[(size_t)i] = n;
+    }
+    return heap[0];
+}
+
+BVH create_bvh(Triangle* triangles, size_t count) {                                 // bvh.c:61-67
+    BVH b; b.triangles = triangles; b.triangle_count = count;
+    b.root = create_bvh_node(triangles, 0, (int)count);
+    return b;
+}
+
+void destroy_bvh_node(BVHNode* node) {                                              // bvh.c:69-73
+    if (!node) return;
+    destroy_bvh_node(node->left);
+    destroy_bvh_node(node->right);
+    free(node);
+}
+
+void destroy_bvh(BVH* bvh) {                                                        // bvh.c:75-78
+    if (!bvh) return;
+    destroy_bvh_node(bvh->root);
+    bvh->root = nullptr;
+}
+
+// ------------------------------------------------------------------ meshes
+Mesh create_mesh(const char* obj_filename, const char* texture_filename) {          // mesh.c:6-119
+    Mesh mesh;
+    memset(&mesh, 0, sizeof(mesh));
+    FILE* f = fopen(obj_filename, "r");
+    if (!f) { fprintf(stderr, "Failed to open %s\n", obj_filename); return mesh; }
+    std::vector<Vec3> pos, nor;
+    std::vector<Vec2> uv;
+    std::vector<Triangle> tris;
+    char buf[4096];
+    while (fgets(buf, sizeof buf, f)) {
+        const char* p = buf;
+        if (p[0] == 'v' && p[1] == ' ') {
+            float v[3] = {0, 0, 0}; read_floats(p + 2, v, 3); pos.push_back(Vec3{v[0], v[1], v[2]});
+        } else if (p[0] == 'v' && p[1] == 't') {
+            float v[2] = {0, 0}; read_floats(p + 3, v, 2); uv.push_back(Vec2{v[0], v[1]});
+        } else if (p[0] == 'v' && p[1] == 'n') {
+            float v[3] = {0, 0, 0}; read_floats(p + 3, v, 3); nor.push_back(Vec3{v[0], v[1], v[2]});
+        } else if (p[0] == 'f') {
+            long c[3][3];
+            const char* q = skip_ws(p + 1);
+            bool ok = true;
+            for (int k = 0; k < 3 && ok; k++) { q = skip_ws(q); ok = read_corner(q, c[k]); }
+            for (int k = 0; k < 3 && ok; k++)
+                ok = c[k][0] >= 1 && (size_t)c[k][0] <= pos.size() && c[k][1] >= 1 && (size_t)c[k][1] <= uv.size() &&
+                     c[k][2] >= 1 && (size_t)c[k][2] <= nor.size();
+            if (!ok) { fprintf(stderr, "%s: skipping face the reader cannot use: %s", obj_filename, buf); continue; }
+            Triangle t;
+            t.v0 = pos[(size_t)c[0][0] - 1]; t.v1 = pos[(size_t)c[1][0] - 1]; t.v2 = pos[(size_t)c[2][0] - 1];
+            t.t0 = uv[(size_t)c[0][1] - 1];  t.t1 = uv[(size_t)c[1][1] - 1];  t.t2 = uv[(size_t)c[2][1] - 1];
+            t.n0 = nor[(size_t)c[0][2] - 1]; t.n1 = nor[(size_t)c[1][2] - 1]; t.n2 = nor[(size_t)c[2][2] - 1];
+            tris.push_back(t);
+        }
+    }
+    fclose(f);
+    mesh.triangles = (Triangle*)malloc(sizeof(Triangle) * (tris.empty() ? 1 : tris.size()));
+    if (!mesh.triangles) return mesh;
+    if (!tris.empty()) memcpy(mesh.triangles, tris.data(), sizeof(Triangle) * tris.size());
+    mesh.triangle_count = tris.size();
+
+    FILE* tf = fopen(texture_filename, "rb");
+    if (!tf) { fprintf(stderr, "Failed to open texture %s\n", texture_filename); return mesh; }
+    fseek(tf, 0, SEEK_END);
+    long size = ftell(tf);
+    fseek(tf, 0, SEEK_SET);
+    std::vector<uint8_t> bytes((size_t)(size > 0 ? size : 0));
+    const bool read_ok = size > 0 && fread(bytes.data(), 1, (size_t)size, tf) == (size_t)size;
+    fclose(tf);
+    if (!read_ok) return mesh;
+    if (!load_webp()) { fprintf(stderr, "create_mesh: libwebp is not available, cannot decode %s\n", texture_filename); return mesh; }
+    mesh.texture_data = g_webp_decode(bytes.data(), bytes.size(), &mesh.texture_width, &mesh.texture_height);   // mesh.c:105
+    if (!mesh.texture_data) { fprintf(stderr, "create_mesh: %s is not a WebP image\n", texture_filename); return mesh; }
+
+    mesh.bvh = create_bvh(mesh.triangles, mesh.triangle_count);                                                  // mesh.c:110
+    printf("Loaded %zu vertices, %zu texcoords, %zu normals, %zu triangles\n", pos.size(), uv.size(), nor.size(), tris.size());
+    return mesh;
+}
+
+void set_mesh_position(Mesh* mesh, Vec3 position) { mesh->transform.position = position; }     // mesh.c:121
+void set_mesh_rotation(Mesh* mesh, Vec3 rotation) { mesh->transform.rotation = rotation; }     // mesh.c:125
+
+void destroy_mesh(Mesh* mesh) {                                                                 // mesh.c:129-136
+    if (!mesh) return;
+    free(mesh->triangles);
+    if (mesh->texture_data) { if (g_webp_free) g_webp_free(mesh->texture_data); else free(mesh->texture_data); }
+    destroy_bvh(&mesh->bvh);
+    mesh->triangles = nullptr; mesh->texture_data = nullptr; mesh->triangle_count = 0;
+}
+
+Vec3 sample_mesh_texture(const Mesh* mesh, float u, float v) {                                  // mesh.c:138-149
+    u = u - floorf(u); v = v - floorf(v);
+    const int x = (int)(u * (float)(mesh->texture_width - 1)), y = (int)(v * (float)(mesh->texture_height - 1));
+    const unsigned char* t = mesh->texture_data + ((size_t)y * (size_t)mesh->texture_width + (size_t)x) * 4;
+    return Vec3{t[0] / 255.0f, t[1] / 255.0f, t[2] / 255.0f};
+}
+
+// ------------------------------------------------------------------ scene
+Scene create_scene(int width, int height, int duration_ms, int fps, float scale_factor) {      // scene.c:8-29
+    Scene s;
+    memset(&s, 0, sizeof(s));
+    s.frame_count = (duration_ms * fps) / 1000;
+    s.width = (int)(width * scale_factor);
+    s.height = (int)(height * scale_factor);
+    s.scale_factor = scale_factor;
+    s.duration_ms = duration_ms; s.fps = fps;
+    // The reference sizes every buffer for the unscaled image (scene.c:25); take the larger of the
+    // two so that scale factors above 1 do not overrun it.
+    size_t px = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);
+    const size_t spx = (size_t)(s.width > 0 ? s.width : 0) * (size_t)(s.height > 0 ? s.height : 0);
+    if (spx > px) px = spx;
+    const int n = s.frame_count > 0 ? s.frame_count : 0;
+    s.frames = (unsigned char**)calloc((size_t)n + 1, sizeof(unsigned char*));
+    for (int i = 0; i < n; i++) s.frames[i] = (unsigned char*)malloc(px * 3 + 1);
+    return s;
+}
+
+void add_mesh_to_scene(Scene* scene, Mesh mesh) {                                              // scene.c:31-35
+    Mesh* grown = (Mesh*)realloc(scene->meshes, (scene->mesh_count + 1) * sizeof(Mesh));
+    if (!grown) return;
+    scene->meshes = grown;
+    scene->meshes[scene->mesh_count++] = mesh;
+}
+
+void set_scene_camera(Scene* scene, Vec3 position, Vec3 look_at, Vec3 up, float fov) {         // scene.c:37
+    scene->camera = create_camera(position, look_at, up, fov);
+}
+
+void set_scene_light(Scene* scene, Vec3 direction, Vec3 color) {                               // scene.c:41
+    scene->light = create_directional_light(direction, color);
+}
+
+void next_frame(Scene* scene) {                                                                 // scene.c:45-50
+    if (++scene->current_frame >= scene->frame_count) scene->current_frame = scene->frame_count - 1;
+}
+
+void render_scene(Scene* scene) {                                                               // scene.c:52-160
+    if (!scene || !scene->frames || scene->current_frame < 0 || scene->current_frame >= scene->frame_count) return;
+    render_into(scene, scene->frames[scene->current_frame], nullptr, nullptr, nullptr);
+}
+
+void save_scene(Scene* scene, const char* filename) {                                           // scene.c:162-225
+    // The reference assembles an animated WebP with libwebpmux, which this image does not ship.
+    // Like the reference when it cannot open its output file, report nothing to the caller.
+    (void)scene;
+    fprintf(stderr, "save_scene: animated WebP encoding is not available in this build; %s not written\n", filename ? filename : "(null)");
+}
+
+void destroy_scene(Scene* scene) {                                                              // scene.c:227-239
+    if (!scene) return;
+    {
+        std::lock_guard<std::mutex> g(g_lock);
+        auto it = g_states.find((const void*)scene->frames);
+        if (it != g_states.end()) {
+            if (it->second.ctx) rt_ctx_destroy(it->second.ctx);
+            g_states.erase(it);
+        }
+    }
+    free(scene->meshes);
+    if (scene->frames) {
+        for (int i = 0; i < scene->frame_count; i++) free(scene->frames[i]);
+        free(scene->frames);
+    }
+    scene->meshes = nullptr; scene->frames = nullptr; scene->mesh_count = 0;
+}
+
+// ------------------------------------------------------------------ additions
+void rt_host_set_device(int device) { std::lock_guard<std::mutex> g(g_lock); g_device = device; }
+
+int rt_host_last_status(const Scene* scene) {
+    std::lock_guard<std::mutex> g(g_lock);
+    SceneState* st = scene ? state_of(scene, false) : nullptr;
+    return st ? st->last_status : RT_ERR_INVALID;
+}
+
+int rt_host_render_debug(Scene* scene, int32_t* hit_id, float* hit_t, uint8_t* shadow) {
+    if (!scene || !scene->frames || scene->current_frame < 0 || scene->current_frame >= scene->frame_count) return RT_ERR_INVALID;
+    return render_into(scene, scene->frames[scene->current_frame], hit_id, hit_t, shadow);
+}
+
+void rt_host_demo_animation(int frame, Transform* drone, Transform* treasure) {
+    // raytracer.c:41: frame * (2.0f * M_PI / 120.0f) is a double product, stored to a float.
+    const float t = (float)(frame * ((double)2.0f * 3.14159265358979323846 / (double)120.0f));
+    if (drone) {
+        drone->position = Vec3{2.0f * cosf(t), 1.0f + 0.2f * sinf(2 * t), 2.0f * sinf(t)};     // raytracer.c:44-45
+        drone->rotation = Vec3{0.1f * sinf(t), t, 0.1f * cosf(t)};                             // raytracer.c:46-47
+    }
+    if (treasure) {
+        treasure->position = Vec3{1.0f, 0.5f + 0.1f * sinf(t), 1.0f};                          // raytracer.c:50-51
+        treasure->rotation = Vec3{0, t * 0.5f, 0};                                             // raytracer.c:52-53
+    }
+}
+
+int rt_host_write_ppm(const Scene* scene, int index, const char* filename) {
+    if (!scene || !filename || index < 0 || index >= scene->frame_count) return RT_ERR_INVALID;
+    FILE* f = fopen(filename, "wb");
+    if (!f) return RT_ERR_INVALID;
+    fprintf(f, "P6\n%d %d\n255\n", scene->width, scene->height);
+    fwrite(scene->frames[index], 1, (size_t)scene->width * (size_t)scene->height * 3, f);
+    fclose(f);
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+/*
+ * raytracer_host.h -- the reference ray tracer's host API, kept name-for-name and
+ * layout-for-layout, on top of the MI355X rendering core (include/rt_mi355.h).
+ *
+ * A program written against the reference's headers (scene.h, geometry/mesh.h, accel/bvh.h,
+ * render/camera.h, render/light.h, utils/image.h) compiles against this one header and links
+ * libraytracer_host.so instead of the reference's objects.  render_scene() runs the frame on
+ * the GPU; there is no CPU rendering path behind it.
+ *
+ * Struct layouts equal the reference's (sizes on LP64 in brackets) because callers reach into
+ * them directly, e.g. scene.meshes[0] in the reference driver (raytracer.c:44).
+ */
+#ifndef RAYTRACER_HOST_H
+#define RAYTRACER_HOST_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z; } Vec3;                                   /* [12] math/vec3.h:6 */
+typedef struct { float u, v; } Vec2;                                      /* [8]  math/vec3.h:7 */
+typedef struct { float m[4][4]; } Mat4;                                   /* [64] math/mat4.h:6-8 */
+typedef struct { Vec3 origin, direction; } Ray;                           /* [24] math/ray.h:8-10 */
+typedef struct { Vec3 position, rotation; } Transform;                    /* [24] math/ray.h:12-15, radians about x,y,z */
+typedef struct { Vec3 min, max; } AABB;                                   /* [24] geometry/aabb.h:9-12 */
+typedef struct { Vec3 v0, v1, v2; Vec2 t0, t1, t2; Vec3 n0, n1, n2; } Triangle;   /* [96] geometry/triangle.h:6-10 */
+typedef struct BVHNode {                                                   /* [48] accel/bvh.h:8-14 */
+    AABB bounds;
+    struct BVHNode* left;
+    struct BVHNode* right;
+    int start_idx, triangle_count;
+} BVHNode;
+typedef struct { BVHNode* root; Triangle* triangles; size_t triangle_count; } BVH;          /* accel/bvh.h:16-20 */
+typedef struct {                                                           /* geometry/mesh.h:11-19 */
+    Triangle* triangles;
+    size_t triangle_count;
+    unsigned char* texture_data;       /* RGBA8 rows as decoded from the WebP file */
+    int texture_width, texture_height;
+    BVH bvh;
+    Transform transform;
+} Mesh;
+typedef struct { Vec3 position, look_at, up; float fov; } Camera;         /* [40] render/camera.h:7-12 */
+typedef struct { Vec3 direction, color; } DirectionalLight;               /* [24] render/light.h:6-9 */
+typedef struct {                                                           /* scene.h:13-26 */
+    Mesh* meshes;
+    size_t mesh_count;
+    Camera camera;
+    DirectionalLight light;
+    unsigned char** frames;            /* frame_count buffers of RGB8, row-major */
+    int frame_count, current_frame;
+    int width, height;
+    float scale_factor;
+    int duration_ms, fps;
+} Scene;
+
+/* scene.h:29-36 */
+Scene create_scene(int width, int height, int duration_ms, int fps, float scale_factor);
+void add_mesh_to_scene(Scene* scene, Mesh mesh);
+void set_scene_camera(Scene* scene, Vec3 position, Vec3 look_at, Vec3 up, float fov);
+void set_scene_light(Scene* scene, Vec3 direction, Vec3 color);
+void next_frame(Scene* scene);
+void render_scene(Scene* scene);       /* GPU; on failure prints to stderr and leaves the frame untouched */
+void save_scene(Scene* scene, const char* filename);
+void destroy_scene(Scene* scene);
+
+/* geometry/mesh.h:22-26 */
+Mesh create_mesh(const char* obj_filename, const char* texture_filename);
+void set_mesh_position(Mesh* mesh, Vec3 position);
+void set_mesh_rotation(Mesh* mesh, Vec3 rotation);
+void destroy_mesh(Mesh* mesh);
+Vec3 sample_mesh_texture(const Mesh* mesh, float u, float v);
+
+/* accel/bvh.h:23-28 */
+BVHNode* create_bvh_node(Triangle* triangles, int start, int count);
+BVH create_bvh(Triangle* triangles, size_t count);
+void destroy_bvh_node(BVHNode* node);
+void destroy_bvh(BVH* bvh);
+
+/* render/camera.h:15, render/light.h:12 */
+Camera create_camera(Vec3 position, Vec3 look_at, Vec3 up, float fov);
+DirectionalLight create_directional_light(Vec3 direction, Vec3 color);
+
+/* ---- additions that the reference does not have ---- */
+/* GPU used by scenes created afterwards on this thread's process (default 0, or $RT_DEVICE). */
+void rt_host_set_device(int device);
+/* Status of the most recent render_scene() on this scene: 0 or a negative rt_status. */
+int rt_host_last_status(const Scene* scene);
+/* Debug planes of the most recent render_scene(): any pointer may be NULL.
+ * hit_id = (mesh<<24)|triangle or -1; hit_t = closest t; shadow = 1 blocked / 0 lit / 255 miss.
+ * Re-renders the current frame with those planes enabled. */
+int rt_host_render_debug(Scene* scene, int32_t* hit_id, float* hit_t, uint8_t* shadow);
+/* Placements of the reference driver's animation at `frame` (raytracer.c:41-53): meshes[0]
+ * (drone) and meshes[1] (treasure); computed with the same float/double mix as the driver. */
+void rt_host_demo_animation(int frame, Transform* drone, Transform* treasure);
+/* Writes frame `index` as a binary PPM (P6). */
+int rt_host_write_ppm(const Scene* scene, int index, const char* filename);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

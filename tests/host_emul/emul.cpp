@@ -1,0 +1,131 @@
+// emul.cpp -- TEST-ONLY host build of the product's pixel pipeline (raytracer_amd/csrc/rt_pixel.h)
+// over the product's packed scene layout (rt_pack.h).  It lets the CPU test-suite check the
+// packer, the stack traversal and the tie rules against the oracle without a GPU.  It is not
+// part of librt_mi355.so and nothing in the product loads it.
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../raytracer_amd/csrc/rt_pack.h"
+#include "../../raytracer_amd/csrc/rt_pixel.h"
+
+using namespace rt;
+
+namespace {
+struct ArrayStack {
+    uint32_t data[kStackDepth];
+    int sp = 0;
+    int high = 0;
+    void clear() { sp = 0; }
+    bool empty() const { return sp == 0; }
+    void push(uint32_t v) { data[sp++] = v; if (sp > high) high = sp; }
+    uint32_t pop() { return data[--sp]; }
+};
+
+struct EmulMesh {
+    PackedMesh pk;
+    std::vector<uint32_t> texels;
+    int tw = 0, th = 0;
+};
+struct EmulScene {
+    std::vector<EmulMesh> meshes;
+    std::string err;
+    int stack_high = 0;
+};
+}  // namespace
+
+extern "C" {
+
+void* emul_scene_create() { return new EmulScene(); }
+void emul_scene_destroy(void* s) { delete (EmulScene*)s; }
+const char* emul_last_error(void* s) { return ((EmulScene*)s)->err.c_str(); }
+int emul_stack_high(void* s) { return ((EmulScene*)s)->stack_high; }
+
+int emul_mesh_add(void* sp, const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes,
+                  const uint8_t* rgba, int32_t tw, int32_t th) {
+    EmulScene* s = (EmulScene*)sp;
+    EmulMesh m;
+    int st = Packer(tris, n_tris, nodes, n_nodes, m.pk).run(s->err);
+    if (st != RT_OK) return st;
+    m.texels.resize((size_t)tw * th);
+    memcpy(m.texels.data(), rgba, (size_t)tw * th * 4);
+    m.tw = tw; m.th = th;
+    s->meshes.push_back(std::move(m));
+    return RT_OK;
+}
+
+int emul_mesh_info(void* sp, int mesh, int32_t* n_pairs, int32_t* depth, uint32_t* root_ref) {
+    EmulScene* s = (EmulScene*)sp;
+    if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;
+    *n_pairs = (int32_t)s->meshes[mesh].pk.pairs.size();
+    *depth = s->meshes[mesh].pk.depth;
+    *root_ref = s->meshes[mesh].pk.root_ref;
+    return RT_OK;
+}
+
+int emul_mesh_prios(void* sp, int mesh, uint32_t* out) {
+    EmulScene* s = (EmulScene*)sp;
+    if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;
+    const auto& t = s->meshes[mesh].pk.tris;
+    for (size_t i = 0; i < t.size(); i++) out[i] = t[i].prio;
+    return RT_OK;
+}
+
+// Per-frame constants as the product computes them: inv rows 0..3 (16 floats) and nrm (9 floats).
+void emul_placement(const rt_transform* tf, const rt_camera* cam, const rt_light* light, float* inv16, float* nrm9,
+                    float* cam_o3, float* lit_d3, uint32_t* w_mode) {
+    FrameArgs A; memset(&A, 0, sizeof A);
+    fill_camera(*cam, *light, 16, 16, A);
+    MeshArgs M; memset(&M, 0, sizeof M);
+    fill_placement(*tf, A, M);
+    memcpy(inv16, M.inv, 48); memcpy(inv16 + 12, M.wrow, 16);
+    memcpy(nrm9, M.nrm, 36);
+    memcpy(cam_o3, M.cam_o, 12); memcpy(lit_d3, M.lit_d, 12);
+    *w_mode = M.w_mode;
+}
+
+int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_transform* tfs, int32_t n_tf,
+                int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_id, float* hit_t, uint8_t* shadow,
+                rt_counters* counters, int32_t full) {
+    EmulScene* s = (EmulScene*)sp;
+    if (n_tf != (int32_t)s->meshes.size() || n_tf > kMaxMeshes) { s->err = "transform count"; return RT_ERR_INVALID; }
+    FrameArgs A; memset(&A, 0, sizeof A);
+    fill_camera(*cam, *light, width, height, A);
+    A.n_mesh = n_tf;
+    for (int m = 0; m < n_tf; m++) {
+        MeshArgs& M = A.mesh[m];
+        const EmulMesh& E = s->meshes[(size_t)m];
+        M.pairs = E.pk.pairs.data(); M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
+        memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
+        M.root_ref = E.pk.root_ref; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        fill_placement(tfs[m], A, M);
+    }
+    unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
+    int high = 0;
+    #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_slab, c_tri, c_hit, c_dark) reduction(max : high)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            ArrayStack st;
+            Work w; w.slabs = 0; w.tris = 0;
+            PixelOut r = full ? shade_pixel<true, true>(A, x, y, st, w) : shade_pixel<true, false>(A, x, y, st, w);
+            const size_t p = (size_t)y * width + x;
+            rgb[p * 3] = r.r; rgb[p * 3 + 1] = r.g; rgb[p * 3 + 2] = r.b;
+            if (hit_id) hit_id[p] = r.hit_id;
+            if (hit_t) hit_t[p] = r.hit_t;
+            if (shadow) shadow[p] = r.shadow;
+            c_slab += w.slabs; c_tri += w.tris; c_hit += r.hit; c_dark += r.dark;
+            if (st.high > high) high = st.high;
+        }
+    }
+    s->stack_high = high;
+    if (counters) {
+        counters->primary_rays = (uint64_t)width * height; counters->shadow_rays = c_hit;
+        counters->slab_tests = c_slab; counters->tri_tests = c_tri;
+        counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
+    }
+    return RT_OK;
+}
+
+}  // extern "C"
