@@ -137,6 +137,12 @@ int rt_last_kernel_ms(rt_ctx* ctx, float* ms);
 /* Counters of the most recent RT_FLAG_COUNT_WORK launch (waits for it). */
 int rt_last_counters(rt_ctx* ctx, rt_counters* out);
 
+/* Tracing aid (no counterpart in the reference): while a buffer is set, every launch records for each
+ * 8x8 pixel tile, in tile order (row-major over ceil(width/8) x ceil(height/8) tiles), two uint64:
+ * the device's constant 100 MHz clock when a wave started and finished that tile.  d_tile_clock
+ * must hold 16 bytes per tile of the frames rendered; NULL switches tracing off. */
+int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
+
 /* Tunables, by name: "variant" (kernel variant id, 0 <= id < "n_variants"), "block" (threads per
  * workgroup: 64, 128 or 256), "timing" (record HIP events around each launch, default 1).
  * Read-only: "n_variants", "default_variant".  Unknown names give RT_ERR_INVALID. */

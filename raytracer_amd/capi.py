@@ -54,6 +54,7 @@ EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_bvh_build", "rt_bvh_flatten_tree",
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
+    "rt_set_trace_buffer",
 ]
 
 _lib = None
@@ -65,12 +66,23 @@ class RtError(RuntimeError):
         super().__init__(f"rt_mi355 status {status} ({status_string(status)}){': ' + detail if detail else ''}")
 
 
+def _load_torch_hip_first():
+    """PyTorch wheels bundle their own HIP runtime (same soname as the system one).  A process that
+    uses both torch and this library must let torch load its copy first: with the system runtime
+    already mapped, torch's device initialisation fails ("No HIP GPUs are available")."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `make product` (hipcc, gfx950); "
                                "there is no CPU fallback")
+        _load_torch_hip_first()
         L = C.CDLL(LIB_PATH)
         vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
         L.rt_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -94,6 +106,7 @@ def lib():
         L.rt_last_counters.argtypes = [vp, C.POINTER(Counters)]
         L.rt_set_option.argtypes = [vp, C.c_char_p, C.c_int]
         L.rt_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
+        L.rt_set_trace_buffer.argtypes = [vp, vp]
         for name in EXPORTS:
             getattr(L, name)          # AttributeError here = the library does not export the ABI
         _lib = L
@@ -211,6 +224,10 @@ class Context:
                                                hid.ctypes.data if debug else None, ht.ctypes.data if debug else None,
                                                sh.ctypes.data if debug else None))
         return rgb, hid, ht, sh
+
+    def set_trace_buffer(self, buf):
+        """Per-tile {start, end} clock trace into a device buffer of 2 uint64 per 8x8 tile (None = off)."""
+        self._check(lib().rt_set_trace_buffer(self._h, _dev_ptr(buf)))
 
     def sync(self, stream: Optional[int] = None):
         self._check(lib().rt_sync(self._h, stream))

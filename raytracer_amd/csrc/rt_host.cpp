@@ -17,7 +17,8 @@ using namespace rt;
 namespace {
 
 struct DeviceMesh {
-    PairNode* d_pairs = nullptr;
+    std::vector<PairNode> pairs;   // host copy; the device copy lives in the scene's combined array
+    int depth = 0;
     TriRec* d_tris = nullptr;
     AttrRec* d_attrs = nullptr;
     uint32_t* d_texels = nullptr;
@@ -33,6 +34,12 @@ struct rt_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool ev_pending = false;
     std::vector<DeviceMesh> meshes;
+    PairNode* d_all_pairs = nullptr;         // PairNodes of all meshes, rebuilt when the mesh list changes
+    uint32_t n_all_pairs = 0;
+    uint32_t stack_entries = 2;
+    bool scene_dirty = true;
+    TileQueue* d_queue = nullptr;
+    void* d_tile_clock = nullptr;            // caller-owned trace buffer (rt_set_trace_buffer)
     DeviceCounters* d_counters = nullptr;
     bool counters_pending = false;
     // planes used by rt_render_frame_host
@@ -40,6 +47,7 @@ struct rt_ctx {
     size_t plane_pixels = 0;
     LaunchConfig cfg;
     int timing = 1;
+    int coop = 1;                  // cooperative rendering of the big meshes' screen area (variant 3)
     std::string err;
 };
 
@@ -63,7 +71,6 @@ int hip_fail(rt_ctx* ctx, hipError_t e, const char* what) {
     } while (0)
 
 void free_mesh(DeviceMesh& m) {
-    if (m.d_pairs) (void)hipFree(m.d_pairs);
     if (m.d_tris) (void)hipFree(m.d_tris);
     if (m.d_attrs) (void)hipFree(m.d_attrs);
     if (m.d_texels) (void)hipFree(m.d_texels);
@@ -78,6 +85,28 @@ int upload_array(rt_ctx* ctx, const std::vector<T>& src, T** dst) {
     RT_HIP(ctx, hipMalloc((void**)dst, bytes));
     if (!src.empty()) RT_HIP(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     else RT_HIP(ctx, hipMemset(*dst, 0, bytes));
+    return RT_OK;
+}
+
+// Rebuilds the combined node array after the mesh list changed.
+int commit_scene(rt_ctx* ctx) {
+    if (!ctx->scene_dirty) return RT_OK;
+    RT_HIP(ctx, hipDeviceSynchronize());              // no launch may still read the old array
+    if (ctx->d_all_pairs) (void)hipFree(ctx->d_all_pairs);
+    ctx->d_all_pairs = nullptr;
+    std::vector<PairNode> all;
+    int depth = 0;
+    for (auto& m : ctx->meshes) {
+        m.proto.pair_base = (uint32_t)all.size();
+        m.proto.pair_count = (uint32_t)m.pairs.size();
+        all.insert(all.end(), m.pairs.begin(), m.pairs.end());
+        if (m.depth > depth) depth = m.depth;
+    }
+    int st = upload_array(ctx, all, &ctx->d_all_pairs);
+    if (st != RT_OK) return st;
+    ctx->n_all_pairs = (uint32_t)all.size();
+    ctx->stack_entries = (uint32_t)depth + 2;        // a chain of `depth` PairNodes holds at most depth+1 entries
+    ctx->scene_dirty = false;
     return RT_OK;
 }
 
@@ -129,6 +158,11 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, sizeof(DeviceCounters));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_queue, sizeof(TileQueue));
+    if (e == hipSuccess) e = hipMemset(ctx->d_queue, 0, sizeof(TileQueue));
+    int cus = 0;
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (e == hipSuccess) { ctx->cfg.queue = ctx->d_queue; ctx->cfg.n_cus = cus > 0 ? cus : 256; }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         rt_ctx_destroy(ctx);
@@ -143,6 +177,8 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& m : ctx->meshes) free_mesh(m);
+    if (ctx->d_all_pairs) (void)hipFree(ctx->d_all_pairs);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
     if (ctx->d_id) (void)hipFree(ctx->d_id);
@@ -184,8 +220,7 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const r
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     DeviceMesh dm;
-    st = upload_array(ctx, pk.pairs, &dm.d_pairs);
-    if (st == RT_OK) st = upload_array(ctx, pk.tris, &dm.d_tris);
+    st = upload_array(ctx, pk.tris, &dm.d_tris);
     if (st == RT_OK) st = upload_array(ctx, pk.attrs, &dm.d_attrs);
     if (st == RT_OK) {
         const size_t bytes = (size_t)tex_width * (size_t)tex_height * 4;
@@ -195,7 +230,8 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const r
     }
     if (st != RT_OK) { free_mesh(dm); return st; }
     memset(&dm.proto, 0, sizeof(dm.proto));
-    dm.proto.pairs = dm.d_pairs; dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs; dm.proto.texels = dm.d_texels;
+    dm.pairs = pk.pairs; dm.depth = pk.depth;
+    dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs; dm.proto.texels = dm.d_texels;
     memcpy(dm.proto.root_min, pk.root_min, 12);
     memcpy(dm.proto.root_max, pk.root_max, 12);
     dm.proto.root_ref = pk.root_ref;
@@ -203,6 +239,7 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const r
     dm.proto.empty = pk.empty ? 1u : 0u;
     dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.pairs.size();
     ctx->meshes.push_back(dm);
+    ctx->scene_dirty = true;
     if (mesh_id) *mesh_id = (int32_t)ctx->meshes.size() - 1;
     return RT_OK;
 }
@@ -223,6 +260,7 @@ int rt_scene_clear(rt_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (auto& m : ctx->meshes) free_mesh(m);
     ctx->meshes.clear();
+    ctx->scene_dirty = true;
     return RT_OK;
 }
 
@@ -238,6 +276,10 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
         return fail(ctx, RT_ERR_INVALID, "one transform per uploaded mesh is required");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int cst = commit_scene(ctx);
+    if (cst != RT_OK) return cst;
+    SceneArgs S;
+    S.pairs = ctx->d_all_pairs; S.n_pairs = ctx->n_all_pairs; S.stack_entries = ctx->stack_entries;
 
     FrameArgs A;
     memset(&A, 0, sizeof(A));
@@ -248,15 +290,46 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
         A.mesh[m] = ctx->meshes[(size_t)m].proto;
         fill_placement(transforms[m], A, A.mesh[m]);
     }
+    // Work layout: screen rectangles where rays can meet a big mesh are rendered cooperatively and
+    // launched first.  Not used when the caller asks for the reference's visiting order or for work
+    // counts, when a rectangle cannot be bounded, or when they cover more than a quarter of the frame.
+    if (ctx->cfg.variant == 3 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER)) == 0 && ctx->coop) {
+        std::vector<WorldBox> boxes((size_t)n_transforms);
+        double slo[3] = {1e300, 1e300, 1e300}, shi[3] = {-1e300, -1e300, -1e300};
+        for (int32_t m = 0; m < n_transforms; m++) {
+            boxes[(size_t)m] = world_box(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max);
+            if (A.mesh[m].empty) continue;
+            for (int i = 0; i < 3; i++) {
+                slo[i] = boxes[(size_t)m].lo[i] < slo[i] ? boxes[(size_t)m].lo[i] : slo[i];
+                shi[i] = boxes[(size_t)m].hi[i] > shi[i] ? boxes[(size_t)m].hi[i] : shi[i];
+            }
+        }
+        bool ok = true;
+        long long area = 0;
+        int n = 0;
+        for (int32_t m = 0; m < n_transforms && ok; m++) {
+            if (A.mesh[m].pair_count < kBigMeshPairs) continue;
+            int r[4];
+            ok = n < kMaxCoopRects && coop_rect(boxes[(size_t)m], slo, shi, A, ctx->coop == 1, r);
+            if (ok && r[2] > r[0] && r[3] > r[1]) {
+                for (int i = 0; i < 4; i++) A.rect[n][i] = r[i];
+                area += (long long)(r[2] - r[0]) * (r[3] - r[1]);
+                n++;
+            }
+        }
+        const long long tiles = (long long)((width + 7) / 8) * ((height + 7) / 8);
+        A.n_rects = (ok && area * 4 <= tiles) ? n : 0;
+    }
     OutputPlanes O;
     O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_id; O.hit_t = (float*)d_hit_t; O.shadow = (uint8_t*)d_shadow;
     O.counters = ctx->d_counters;
+    O.tile_clock = (unsigned long long*)ctx->d_tile_clock;
     if (flags & RT_FLAG_COUNT_WORK) {
         RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DeviceCounters), s));
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    RT_HIP(ctx, launch_render(A, O, ctx->cfg, s));
+    RT_HIP(ctx, launch_render(A, S, O, ctx->cfg, s));
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
     return RT_OK;
 }
@@ -311,6 +384,12 @@ int rt_last_counters(rt_ctx* ctx, rt_counters* out) {
     return RT_OK;
 }
 
+int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->d_tile_clock = d_tile_clock;
+    return RT_OK;
+}
+
 int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return RT_ERR_INVALID;
     if (!strcmp(name, "variant")) {
@@ -322,6 +401,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
         ctx->cfg.block = value; return RT_OK;
     }
     if (!strcmp(name, "timing")) { ctx->timing = value ? 1 : 0; return RT_OK; }
+    if (!strcmp(name, "coop")) { ctx->coop = value; return RT_OK; }
     return fail(ctx, RT_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -330,6 +410,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "variant")) { *value = ctx->cfg.variant; return RT_OK; }
     if (!strcmp(name, "block")) { *value = ctx->cfg.block; return RT_OK; }
     if (!strcmp(name, "timing")) { *value = ctx->timing; return RT_OK; }
+    if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
     if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }
     if (!strcmp(name, "default_variant")) { *value = kDefaultVariant; return RT_OK; }
     return RT_ERR_INVALID;

@@ -7,17 +7,25 @@
 
 namespace rt {
 
-constexpr int kNumVariants = 1;      // kernel variants selectable through LaunchConfig::variant
-constexpr int kDefaultVariant = 0;
+constexpr int kNumVariants = 4;      // kernel variants selectable through LaunchConfig::variant
+constexpr int kDefaultVariant = 3;
+constexpr size_t kMaxLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 
 struct LaunchConfig {
     int variant = kDefaultVariant;   // kernel variant id (see rt_kernels.hip)
-    int block = 256;     // threads per workgroup
+    int block = 256;                 // threads per workgroup (variant 0)
+    int n_cus = 256;                 // compute units of the device (grid of the persistent variant)
+    TileQueue* queue = nullptr;      // zero-initialised device words owned by the context
 };
 
+// True when the scene's nodes and the traversal stacks of one workgroup fit in LDS.
+bool resident_fits(const SceneArgs& S);
+
 // Enqueues one frame on `stream`.  Shapes are validated by the caller (rt_host.cpp):
-// every MeshArgs pointer is a live device allocation sized for its BVH, A.n_mesh <= kMaxMeshes,
-// O.rgb holds width*height*3 bytes and the optional planes width*height elements.
-hipError_t launch_render(const FrameArgs& A, const OutputPlanes& O, const LaunchConfig& cfg, hipStream_t stream);
+// S.pairs holds S.n_pairs records and every MeshArgs range lies inside it, tris/attrs/texels are
+// live device allocations sized for their mesh, A.n_mesh <= kMaxMeshes, O.rgb holds
+// width*height*3 bytes and the optional planes width*height elements.  Launches that share a
+// TileQueue must be ordered one after another (same stream, or synchronised by the caller).
+hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, const LaunchConfig& cfg, hipStream_t stream);
 
 }  // namespace rt

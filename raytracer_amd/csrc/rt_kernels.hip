@@ -2,6 +2,18 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (float results are compared
 // bit-for-bit with a CPU build that has no FMA contraction).
+//
+// Variants (LaunchConfig::variant):
+//   0  render_direct   one thread per pixel, one 8x8 tile per wave, nodes read through the
+//                      vector cache.  Works for any scene the packer accepts.
+//   1  render_resident persistent workgroups, one per CU, 16 waves each.  The PairNodes of the
+//                      whole scene are staged into LDS once per workgroup, next to the per-lane
+//                      traversal stacks; waves pull 8x8 tiles from an atomic counter until the
+//                      frame is done.  Used when nodes + stacks fit in the CU's 160 KB of LDS.
+//   2  render_resident with static tile assignment (wave w of W takes tiles w, w+W, ...).
+//   3  render_tiles    variant 0 plus cooperative rendering of the screen area of big meshes:
+//                      there a wave renders 8 pixels, each by 8 lanes that share the ray's
+//                      traversal stack, and those waves are launched first.  (Default.)
 #include <hip/hip_runtime.h>
 
 #include "rt_kernels.h"
@@ -13,12 +25,18 @@ namespace rt {
 // touch 64 consecutive dwords on every push/pop (no bank conflicts).
 template <int BLOCK>
 struct LdsStack {
-    uint32_t* base;      // &lds[threadIdx.x]
+    uint32_t* base;      // &stack_area[threadIdx.x]
     int sp;
     __device__ __forceinline__ void clear() { sp = 0; }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
     __device__ __forceinline__ void push(uint32_t v) { base[sp * BLOCK] = v; sp++; }
     __device__ __forceinline__ uint32_t pop() { sp--; return base[sp * BLOCK]; }
+};
+
+// PairNodes staged in LDS.
+struct LdsNodes {
+    const PairNode* all;
+    __device__ __forceinline__ const PairNode& operator()(const MeshArgs& M, uint32_t ref) const { return all[M.pair_base + ref]; }
 };
 
 // Pixel of (tile, lane): a wave owns an 8x8 tile, lanes row-major inside it, so the rays of a
@@ -44,12 +62,13 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
-__device__ __forceinline__ void flush_counters(DeviceCounters* c, bool active, const PixelOut& r, const Work& w) {
-    const unsigned long long prim = wave_sum(active ? 1ull : 0ull);
-    const unsigned long long hit = wave_sum(active ? (unsigned long long)r.hit : 0ull);
-    const unsigned long long dark = wave_sum(active ? (unsigned long long)r.dark : 0ull);
-    const unsigned long long slabs = wave_sum(active ? (unsigned long long)w.slabs : 0ull);
-    const unsigned long long tris = wave_sum(active ? (unsigned long long)w.tris : 0ull);
+struct LaneTotals {
+    unsigned long long pixels, hits, darks, slabs, tris;
+};
+
+__device__ __forceinline__ void flush_counters(DeviceCounters* c, const LaneTotals& t) {
+    const unsigned long long prim = wave_sum(t.pixels), hit = wave_sum(t.hits), dark = wave_sum(t.darks);
+    const unsigned long long slabs = wave_sum(t.slabs), tris = wave_sum(t.tris);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&c->primary_rays, prim);
         atomicAdd(&c->shadow_rays, hit);
@@ -64,11 +83,12 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* c, bool active, c
 // Variant 0: one thread per pixel, scene read through the vector cache.
 // ------------------------------------------------------------------------------------------
 template <int BLOCK, bool COUNT, bool FULL>
-__global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const OutputPlanes O) {
+__global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const SceneArgs S, const OutputPlanes O) {
     __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
     LdsStack<BLOCK> stack;
     stack.base = &lds_stack[threadIdx.x];
     stack.sp = 0;
+    GlobalNodes nodes; nodes.all = S.pairs;
 
     const int tiles_x = (A.width + 7) >> 3;
     const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -76,38 +96,372 @@ __global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const 
     tile_pixel(tile, threadIdx.x & 63, tiles_x, px, py);
     const bool active = px < A.width && py < A.height;
 
-    Work work; work.slabs = 0; work.tris = 0;
-    PixelOut r; r.hit = 0; r.dark = 0;
+    LaneTotals tot = {0, 0, 0, 0, 0};
+    const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
     if (active) {
-        r = shade_pixel<COUNT, FULL>(A, px, py, stack, work);
+        Work work; work.slabs = 0; work.tris = 0;
+        const PixelOut r = shade_pixel<COUNT, FULL>(A, nodes, Solo(), px, py, stack, work);
         store_pixel(O, A.width, px, py, r);
+        tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
     }
-    if (COUNT) flush_counters(O.counters, active, r, work);
+    if (O.tile_clock && (threadIdx.x & 63) == 0 && tile < tiles_x * ((A.height + 7) >> 3)) {
+        O.tile_clock[2 * (size_t)tile] = t_start;
+        O.tile_clock[2 * (size_t)tile + 1] = wall_clock64();
+    }
+    if (COUNT) flush_counters(O.counters, tot);
 }
 
 template <int BLOCK>
-static hipError_t launch_direct(const FrameArgs& A, const OutputPlanes& O, bool count, bool full, hipStream_t stream) {
+static hipError_t launch_direct(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, bool count, bool full, hipStream_t stream) {
     const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
     const int waves_per_block = BLOCK / 64;
     const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
-    if (count && full)  hipLaunchKernelGGL((render_direct<BLOCK, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, O);
-    else if (count)     hipLaunchKernelGGL((render_direct<BLOCK, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, O);
-    else if (full)      hipLaunchKernelGGL((render_direct<BLOCK, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, O);
-    else                hipLaunchKernelGGL((render_direct<BLOCK, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, O);
+    if (count && full)  hipLaunchKernelGGL((render_direct<BLOCK, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    else if (count)     hipLaunchKernelGGL((render_direct<BLOCK, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    else if (full)      hipLaunchKernelGGL((render_direct<BLOCK, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    else                hipLaunchKernelGGL((render_direct<BLOCK, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     return hipGetLastError();
 }
 
-hipError_t launch_render(const FrameArgs& A, const OutputPlanes& O, const LaunchConfig& cfg, hipStream_t stream) {
+// ------------------------------------------------------------------------------------------
+// Variant 3: tiles, with cooperative groups where rays are long.
+//
+// A ray through a big mesh visits hundreds of nodes (the reference's traversal has no distance
+// culling to speak of on such meshes), one after the other when a single lane walks it: the few
+// tiles that cover such a mesh then run longer than the rest of the frame takes.  In those tiles
+// a ray is given to kGroupLanes = 8 adjacent lanes.  They keep ONE stack of pending nodes in LDS:
+// each round every lane pops a different node, tests it, and the survivors are pushed back with
+// offsets from a ballot, so the walk is 8 nodes wide and nothing is visited twice.  PairNodes and
+// leaves wait on separate stacks so that a round is all box tests or all triangle tests.  The set
+// of visited nodes is the one a single lane would visit (up to culling, which never changes the
+// result), and the winner is chosen by (t, priority), so the outcome does not depend on the order.
+// ------------------------------------------------------------------------------------------
+constexpr int kCoopPairCap = 7 * 32;     // entries of the group's 256-entry LDS area used for PairNodes
+static_assert(kCoopPairCap + 32 == kStackDepth * kGroupLanes, "the other 32 entries hold pending leaves (at most 23)");
+constexpr int kCoopNarrowAt = kCoopPairCap - 2 * kGroupLanes - kStackDepth;   // see pair round
+
+template <int BLOCK>
+struct CoopGroup {
+    uint32_t lane;          // lane in the wave; the group is lanes [lane & ~7, lane | 7]
+    uint32_t* area;         // LDS: this group's 8 columns of the workgroup's stack area
+
+    // The group's area is rows of 8 adjacent dwords, BLOCK dwords apart: entry i -> row i/8, column i%8.
+    __device__ __forceinline__ uint32_t& pair_slot(int i) const { return area[(i >> 3) * BLOCK + (i & 7)]; }
+    __device__ __forceinline__ uint32_t& leaf_slot(int i) const { return area[((kCoopPairCap + i) >> 3) * BLOCK + (i & 7)]; }
+
+    // Bits of the group's 8 lanes in a wave-wide ballot.
+    __device__ __forceinline__ uint32_t group_bits(unsigned long long votes) const { return (uint32_t)(votes >> (lane & ~7u)) & 0xFFu; }
+
+    template <bool ANY, class Nodes>
+    __device__ __forceinline__ bool run(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& out) const {
+        constexpr bool CULL = !ANY;
+        const uint32_t j = lane & 7u;
+        const uint32_t below = (1u << j) - 1u;
+        Work unused; unused.slabs = 0; unused.tris = 0;
+        Query q;
+        // All lanes of the group hold the same ray, so this is uniform over the group.
+        const bool start = begin_query<ANY, false, false>(M, o, inv, bound, q, unused);
+        int n_pair = 0, n_leaf = 0;
+        if (start) {
+            if (M.root_ref & kLeafBit) { n_leaf = 1; if (j == 0) leaf_slot(0) = M.root_ref; }
+            else { n_pair = 1; if (j == 0) pair_slot(0) = M.root_ref; }
+        }
+        bool done = false;      // any-hit: the group has its answer
+        for (;;) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // stack writes of the previous round
+            __builtin_amdgcn_wave_barrier();
+            const bool leaf_round = __any(n_leaf >= kGroupLanes) || !__any(n_pair > 0);
+            if (leaf_round) {
+                if (!__any(n_leaf > 0)) break;                          // nothing pending in any group of the wave
+                const int take = n_leaf < kGroupLanes ? n_leaf : kGroupLanes;
+                bool stop = false;
+                if ((int)j < take) stop = test_leaf<ANY, false, false>(M, leaf_slot(n_leaf - 1 - (int)j), o, d, q, unused);
+                n_leaf -= take;
+                if (ANY) {
+                    if (group_bits(__ballot(stop)) != 0) { done = true; n_leaf = 0; n_pair = 0; }
+                } else {
+                    // share the closest distance found so far inside the group: it only tightens culling
+                    float lim = q.limit;
+                    lim = fminf(lim, __shfl_xor(lim, 1, 64));
+                    lim = fminf(lim, __shfl_xor(lim, 2, 64));
+                    lim = fminf(lim, __shfl_xor(lim, 4, 64));
+                    q.limit = lim;
+                }
+            } else {
+                // Near the capacity of the pair stack only one lane pops: a round then adds at most
+                // one entry and goes one level down, so at most kStackDepth more can accumulate.
+                const bool narrow = __any(n_pair > kCoopNarrowAt);
+                const int width = narrow ? 1 : kGroupLanes;
+                const int take = n_pair < width ? n_pair : width;
+                bool pl = false, pr = false, ll = false, lr = false;
+                uint32_t lref = 0, rref = 0;
+                if ((int)j < take) {
+                    const PairNode& N = nodes(M, pair_slot(n_pair - 1 - (int)j));
+                    float tl, tr;
+                    bool hl = slab_t(o, inv, N.lmin, N.lmax, tl);
+                    bool hr = slab_t(o, inv, N.rmin, N.rmax, tr);
+                    if (CULL) { hl = hl && !(tl > q.limit); hr = hr && !(tr > q.limit); }
+                    lref = N.lref; rref = N.rref;
+                    pl = hl && !(lref & kLeafBit); ll = hl && (lref & kLeafBit);
+                    pr = hr && !(rref & kLeafBit); lr = hr && (rref & kLeafBit);
+                }
+                n_pair -= take;
+                const uint32_t bpl = group_bits(__ballot(pl)), bpr = group_bits(__ballot(pr));
+                const uint32_t bll = group_bits(__ballot(ll)), blr = group_bits(__ballot(lr));
+                if (pl) pair_slot(n_pair + __popc(bpl & below)) = lref;
+                if (pr) pair_slot(n_pair + __popc(bpl) + __popc(bpr & below)) = rref;
+                n_pair += __popc(bpl) + __popc(bpr);
+                if (ll) leaf_slot(n_leaf + __popc(bll & below)) = lref;
+                if (lr) leaf_slot(n_leaf + __popc(bll) + __popc(blr & below)) = rref;
+                n_leaf += __popc(bll) + __popc(blr);
+            }
+        }
+        if (ANY) return done;
+        // butterfly over the 8 lanes: afterwards every lane holds the group's winner
+        bool found = q.found;
+        Hit h = q.hit;
+        for (int off = 1; off < kGroupLanes; off <<= 1) {
+            Hit other;
+            other.t = __shfl_xor(h.t, off, 64);
+            other.u = __shfl_xor(h.u, off, 64);
+            other.v = __shfl_xor(h.v, off, 64);
+            other.tri = (uint32_t)__shfl_xor((int)h.tri, off, 64);
+            other.prio = (uint32_t)__shfl_xor((int)h.prio, off, 64);
+            const bool other_found = __shfl_xor((int)found, off, 64) != 0;
+            if (beats(other_found, other, found, h)) { h = other; found = true; }
+        }
+        out = h;
+        return found;
+    }
+
+    template <bool COUNT, bool FULL, class Stack, class Nodes>
+    __device__ __forceinline__ bool closest(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound,
+                                            Hit& h, Stack&, Work&) const {
+        return run<false>(M, nodes, o, d, inv, bound, h);
+    }
+    template <bool COUNT, bool FULL, class Stack, class Nodes>
+    __device__ __forceinline__ bool any(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, Stack&, Work&) const {
+        Hit h = no_hit();
+        return run<true>(M, nodes, o, d, inv, 1e30f, h);
+    }
+};
+
+__device__ __forceinline__ bool in_rect(const int32_t* r, int tx, int ty) { return tx >= r[0] && tx < r[2] && ty >= r[1] && ty < r[3]; }
+
+template <int BLOCK, bool COUNT, bool FULL>
+__global__ void __launch_bounds__(BLOCK) render_tiles(const FrameArgs A, const SceneArgs S, const OutputPlanes O) {
+    __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
+    GlobalNodes nodes; nodes.all = S.pairs;
+
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (A.width + 7) >> 3, tiles_y = (A.height + 7) >> 3;
+    int wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
+    LaneTotals tot = {0, 0, 0, 0, 0};
+    int tile = -1;
+
+    // Wave index space: [rect 0: 8 waves per tile][rect 1] ... [all tiles, one wave each].
+    // A tile that lies in several rectangles is rendered by the first; the others' waves, and
+    // the one-wave-per-tile wave of any cooperative tile, have nothing to do.
+    bool coop = false;
+    int tx = 0, ty = 0, sub = 0;
+    for (int r = 0; r < A.n_rects; r++) {
+        const int w = A.rect[r][2] - A.rect[r][0], h = A.rect[r][3] - A.rect[r][1];
+        const int n = w * h * kGroupLanes;
+        if (wave < n) {
+            const int t = wave >> 3;
+            sub = wave & 7;
+            ty = A.rect[r][1] + t / w; tx = A.rect[r][0] + t % w;
+            coop = true;
+            for (int e = 0; e < r; e++) if (in_rect(A.rect[e], tx, ty)) coop = false;
+            if (!coop) return;
+            break;
+        }
+        wave -= n;
+    }
+    if (coop) {
+        const int p = lane >> 3;                       // pixel of this wave: a 4 wide, 2 high block of the tile
+        const int px = tx * 8 + (sub & 1) * 4 + (p & 3);
+        const int py = ty * 8 + (sub >> 1) * 2 + (p >> 2);
+        if (sub == 0) tile = ty * tiles_x + tx;
+        if (px < A.width && py < A.height) {
+            CoopGroup<BLOCK> party;
+            party.lane = (uint32_t)lane;
+            party.area = &lds_stack[threadIdx.x & ~7u];
+            LdsStack<BLOCK> unused_stack; unused_stack.base = nullptr; unused_stack.sp = 0;
+            Work work; work.slabs = 0; work.tris = 0;
+            const PixelOut r = shade_pixel<false, false>(A, nodes, party, px, py, unused_stack, work);
+            if ((lane & 7) == 0) store_pixel(O, A.width, px, py, r);
+        }
+    } else {
+        if (wave >= tiles_x * tiles_y) return;
+        ty = wave / tiles_x; tx = wave - ty * tiles_x;
+        for (int e = 0; e < A.n_rects; e++) if (in_rect(A.rect[e], tx, ty)) return;
+        tile = wave;
+        const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+        if (px < A.width && py < A.height) {
+            LdsStack<BLOCK> stack;
+            stack.base = &lds_stack[threadIdx.x];
+            stack.sp = 0;
+            Work work; work.slabs = 0; work.tris = 0;
+            const PixelOut r = shade_pixel<COUNT, FULL>(A, nodes, Solo(), px, py, stack, work);
+            store_pixel(O, A.width, px, py, r);
+            tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
+        }
+    }
+    if (O.tile_clock && lane == 0 && tile >= 0) {
+        O.tile_clock[2 * (size_t)tile] = t_start;
+        O.tile_clock[2 * (size_t)tile + 1] = wall_clock64();
+    }
+    if (COUNT) flush_counters(O.counters, tot);
+}
+
+template <int BLOCK>
+static hipError_t launch_tiles(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, bool count, bool full, hipStream_t stream) {
+    long long waves = (long long)((A.width + 7) / 8) * ((A.height + 7) / 8);
+    if ((count || full) && A.n_rects != 0) return hipErrorInvalidValue;       // cooperative tiles do not count work
+    for (int r = 0; r < A.n_rects; r++) {
+        const long long w = A.rect[r][2] - A.rect[r][0], h = A.rect[r][3] - A.rect[r][1];
+        if (w <= 0 || h <= 0) return hipErrorInvalidValue;
+        waves += w * h * kGroupLanes;
+    }
+    const int waves_per_block = BLOCK / 64;
+    const int blocks = (int)((waves + waves_per_block - 1) / waves_per_block);
+    if (count && full)  hipLaunchKernelGGL((render_tiles<BLOCK, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    else if (count)     hipLaunchKernelGGL((render_tiles<BLOCK, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    else if (full)      hipLaunchKernelGGL((render_tiles<BLOCK, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    else                hipLaunchKernelGGL((render_tiles<BLOCK, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Variants 1 and 2: persistent workgroups with the scene's nodes resident in LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int kResidentBlock = 1024;     // 16 waves: one workgroup per CU
+constexpr int kTileChunk = 4;            // tiles handed out per atomic
+
+// SCHED 0: tiles handed out dynamically, kTileChunk at a time, from one atomic counter; the next
+//          chunk is requested before the current one is processed.
+// SCHED 1: static assignment, wave w of W takes tiles w, w+W, w+2W, ...
+template <bool COUNT, bool FULL, int SCHED>
+__global__ void __launch_bounds__(kResidentBlock) render_resident(const FrameArgs A, const SceneArgs S, const OutputPlanes O,
+                                                                  TileQueue* queue, const int n_tiles) {
+    extern __shared__ uint4 lds_raw[];
+    // [ PairNode x n_pairs ][ stack: entries x 1024 dwords ]
+    PairNode* lds_nodes = reinterpret_cast<PairNode*>(lds_raw);
+    uint32_t* lds_stack = reinterpret_cast<uint32_t*>(lds_raw + (size_t)S.n_pairs * (sizeof(PairNode) / sizeof(uint4)));
+
+    const uint4* src = reinterpret_cast<const uint4*>(S.pairs);
+    const int n16 = (int)S.n_pairs * (int)(sizeof(PairNode) / sizeof(uint4));
+    for (int i = threadIdx.x; i < n16; i += kResidentBlock) lds_raw[i] = src[i];
+    __syncthreads();
+
+    LdsStack<kResidentBlock> stack;
+    stack.base = &lds_stack[threadIdx.x];
+    stack.sp = 0;
+    LdsNodes nodes; nodes.all = lds_nodes;
+
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (A.width + 7) >> 3;
+    LaneTotals tot = {0, 0, 0, 0, 0};
+
+    auto do_tile = [&](int tile) {
+        int px, py;
+        tile_pixel(tile, lane, tiles_x, px, py);
+        const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
+        if (px < A.width && py < A.height) {
+            Work work; work.slabs = 0; work.tris = 0;
+            const PixelOut r = shade_pixel<COUNT, FULL>(A, nodes, Solo(), px, py, stack, work);
+            store_pixel(O, A.width, px, py, r);
+            if (COUNT) { tot.pixels += 1; tot.hits += r.hit; tot.darks += r.dark; tot.slabs += work.slabs; tot.tris += work.tris; }
+        }
+        if (O.tile_clock && lane == 0) {
+            O.tile_clock[2 * (size_t)tile] = t_start;
+            O.tile_clock[2 * (size_t)tile + 1] = wall_clock64();
+        }
+    };
+
+    if (SCHED == 1) {
+        const int total_waves = (int)gridDim.x * (kResidentBlock / 64);
+        for (int tile = (int)blockIdx.x * (kResidentBlock / 64) + (int)(threadIdx.x >> 6); tile < n_tiles; tile += total_waves) do_tile(tile);
+    } else {
+        unsigned int ticket = 0;
+        if (lane == 0) ticket = atomicAdd(&queue->next, (unsigned int)kTileChunk);
+        for (;;) {
+            const int base = (int)__builtin_amdgcn_readfirstlane(ticket);
+            if (base >= n_tiles) break;             // every wave reaches this: the counter only grows
+            if (lane == 0) ticket = atomicAdd(&queue->next, (unsigned int)kTileChunk);
+            for (int k = 0; k < kTileChunk; k++)
+                if (base + k < n_tiles) do_tile(base + k);
+        }
+        // The last wave of the grid to get here resets the queue for the next launch.  All waves
+        // have stopped taking tiles by then, and the stores are visible at the kernel boundary.
+        if (lane == 0) {
+            const unsigned int total_waves = gridDim.x * (kResidentBlock / 64);
+            const unsigned int d = atomicAdd(&queue->done, 1u);
+            if (d == total_waves - 1) {
+                atomicExch(&queue->next, 0u);
+                atomicExch(&queue->done, 0u);
+            }
+        }
+    }
+    if (COUNT) flush_counters(O.counters, tot);
+}
+
+size_t resident_lds_bytes(const SceneArgs& S) {
+    return (size_t)S.n_pairs * sizeof(PairNode) + (size_t)S.stack_entries * kResidentBlock * sizeof(uint32_t);
+}
+
+template <int SCHED>
+static hipError_t launch_resident(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, const LaunchConfig& cfg,
+                                  bool count, bool full, hipStream_t stream) {
+    const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
+    const size_t lds = resident_lds_bytes(S);
+    int grid = cfg.n_cus > 0 ? cfg.n_cus : 256;
+    const int waves = kResidentBlock / 64;
+    if ((long long)grid * waves > tiles) grid = (tiles + waves - 1) / waves;
+    void (*kern)(const FrameArgs, const SceneArgs, const OutputPlanes, TileQueue*, const int) =
+        count ? (full ? render_resident<true, true, SCHED> : render_resident<true, false, SCHED>)
+              : (full ? render_resident<false, true, SCHED> : render_resident<false, false, SCHED>);
+    // Dynamic LDS beyond 64 KB has to be enabled per kernel function and device; done once each.
+    static bool enabled[16][4] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const int which = (count ? 2 : 0) + (full ? 1 : 0);
+    if (dev < 0 || dev >= 16 || !enabled[dev][which]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 16) enabled[dev][which] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kResidentBlock), lds, stream, A, S, O, cfg.queue, tiles);
+    return hipGetLastError();
+}
+
+bool resident_fits(const SceneArgs& S) { return resident_lds_bytes(S) <= kMaxLdsBytes; }
+
+hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, const LaunchConfig& cfg, hipStream_t stream) {
     if (A.width <= 0 || A.height <= 0) return hipErrorInvalidValue;
     const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
     const bool full = (A.flags & RT_FLAG_REFERENCE_ORDER) != 0;
     if (count && !O.counters) return hipErrorInvalidValue;
-    switch (cfg.variant) {
+    int variant = cfg.variant;
+    if ((variant == 1 || variant == 2) && (!cfg.queue || !resident_fits(S))) variant = 0;     // scene too large for LDS
+    if (variant != 3 && A.n_rects != 0) return hipErrorInvalidValue;
+    switch (variant) {
+        case 1:
+            return launch_resident<0>(A, S, O, cfg, count, full, stream);
+        case 2:
+            return launch_resident<1>(A, S, O, cfg, count, full, stream);
+        case 3:
+            if (cfg.block == 64) return launch_tiles<64>(A, S, O, count, full, stream);
+            if (cfg.block == 128) return launch_tiles<128>(A, S, O, count, full, stream);
+            return launch_tiles<256>(A, S, O, count, full, stream);
         case 0:
         default:
-            if (cfg.block == 64) return launch_direct<64>(A, O, count, full, stream);
-            if (cfg.block == 128) return launch_direct<128>(A, O, count, full, stream);
-            return launch_direct<256>(A, O, count, full, stream);
+            if (cfg.block == 64) return launch_direct<64>(A, S, O, count, full, stream);
+            if (cfg.block == 128) return launch_direct<128>(A, S, O, count, full, stream);
+            return launch_direct<256>(A, S, O, count, full, stream);
     }
 }
 

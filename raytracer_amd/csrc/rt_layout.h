@@ -24,6 +24,13 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr int kMaxLeafTris = 127;
 inline constexpr uint32_t leaf_ref(uint32_t start, uint32_t count) { return kLeafBit | (count << 24) | start; }
 
+// Lanes that share one ray in the cooperative traversal (rt_kernels.hip).
+constexpr int kGroupLanes = 8;
+// A mesh with at least this many PairNodes counts as "big": single rays can visit hundreds of its
+// nodes, so the screen area it covers (and shadows) is rendered cooperatively.
+constexpr uint32_t kBigMeshPairs = 64;
+constexpr int kMaxCoopRects = 4;
+
 struct alignas(64) PairNode {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];
@@ -53,7 +60,8 @@ static_assert(sizeof(AttrRec) == 64, "AttrRec must be one 64-byte record");
 // reference re-derives for every ray (ray.c:5-16, 27-37), computed once per frame on the host
 // with the same float operations.
 struct MeshArgs {
-    const PairNode* pairs;
+    uint32_t pair_base;          // first PairNode of this mesh in the scene's combined node array
+    uint32_t pair_count;
     const TriRec* tris;
     const AttrRec* attrs;
     const uint32_t* texels;      // RGBA8 packed little-endian: R in bits 0..7
@@ -79,11 +87,31 @@ struct FrameArgs {
     float cam_right[3], cam_up[3], cam_fwd[3];
     float aspect, scale;
     float light_dir[3], light_color[3];
+    // Tiles (8x8 pixels) inside any of these rectangles {x0, y0, x1, y1} (tile units, half open) are
+    // rendered cooperatively: eight waves per tile, eight pixels per wave, every pixel's rays
+    // traversed by kGroupLanes lanes together; those waves are launched first.  The rectangles
+    // cover the screen area where a ray, primary or shadow, can meet a big mesh.
+    int32_t n_rects;
+    int32_t rect[kMaxCoopRects][4];
     MeshArgs mesh[kMaxMeshes];
 };
 
 struct DeviceCounters {          // accumulated with atomics when counting is requested
     unsigned long long primary_rays, shadow_rays, slab_tests, tri_tests, hit_pixels, shadowed_pixels;
+};
+
+// Scene-wide device data (valid for every frame until the meshes change).
+struct SceneArgs {
+    const PairNode* pairs;       // PairNodes of all meshes, mesh after mesh
+    uint32_t n_pairs;
+    uint32_t stack_entries;      // traversal stack entries per lane that the deepest mesh needs
+};
+
+// Work distribution state of the persistent kernels: tiles are handed out by an atomic counter;
+// the last wave to finish puts both words back to zero for the next launch.
+struct TileQueue {
+    unsigned int next;
+    unsigned int done;
 };
 
 struct OutputPlanes {
@@ -92,6 +120,7 @@ struct OutputPlanes {
     float* hit_t;
     uint8_t* shadow;
     DeviceCounters* counters;
+    unsigned long long* tile_clock;   // optional trace: per 8x8 tile {start, end} of the constant 100 MHz clock
 };
 
 }  // namespace rt

@@ -259,7 +259,64 @@ inline void fill_placement(const rt_transform& tf, const FrameArgs& A, MeshArgs&
     // w33 exactly for every finite point.
     M.w_mode = 0;
     if (M.wrow[0] == 0.0f && M.wrow[1] == 0.0f && M.wrow[2] == 0.0f && M.wrow[3] != 0.0f) M.w_mode = (M.wrow[3] == 1.0f) ? 2u : 1u;
-    M.pad = 0;
+}
+
+// ---- work layout helpers (never used for results) -------------------------------------------
+struct WorldBox { double lo[3], hi[3]; double corner[8][3]; };
+
+// World-space corners and bounds of a mesh-space box placed by tf.
+inline WorldBox world_box(const rt_transform& tf, const float* bmin, const float* bmax) {
+    const M4 rot = m4_mul(m4_rotation(2, tf.rotation.z), m4_mul(m4_rotation(1, tf.rotation.y), m4_rotation(0, tf.rotation.x)));
+    const M4 fwd = m4_mul(m4_translation(f3(tf.position)), rot);
+    WorldBox w;
+    for (int i = 0; i < 3; i++) { w.lo[i] = 1e300; w.hi[i] = -1e300; }
+    for (int c = 0; c < 8; c++) {
+        const double p[3] = {(c & 1) ? bmax[0] : bmin[0], (c & 2) ? bmax[1] : bmin[1], (c & 4) ? bmax[2] : bmin[2]};
+        for (int i = 0; i < 3; i++) {
+            const double v = fwd.m[i][0] * p[0] + fwd.m[i][1] * p[1] + fwd.m[i][2] * p[2] + fwd.m[i][3];
+            w.corner[c][i] = v;
+            w.lo[i] = v < w.lo[i] ? v : w.lo[i];
+            w.hi[i] = v > w.hi[i] ? v : w.hi[i];
+        }
+    }
+    return w;
+}
+
+// Screen rectangle, in 8x8-pixel tiles {x0, y0, x1, y1} (half open), of every point from which a ray
+// can meet the box `b`: the box itself (camera rays) and the box swept against the light direction
+// as far as the scene's bounds reach (points whose shadow ray can enter it).  Two pixels of margin.
+// Returns false if the region cannot be bounded on screen (a point at or behind the camera plane).
+inline bool coop_rect(const WorldBox& b, const double scene_lo[3], const double scene_hi[3], const FrameArgs& A, bool with_shadow, int rect[4]) {
+    double s_max = 1e300;
+    for (int i = 0; i < 3; i++) {
+        const double L = A.light_dir[i];
+        if (L > 0) { const double s = (b.hi[i] - scene_lo[i]) / L; s_max = s < s_max ? s : s_max; }
+        else if (L < 0) { const double s = (scene_hi[i] - b.lo[i]) / -L; s_max = s < s_max ? s : s_max; }
+    }
+    if (!(s_max > 0)) s_max = 0;
+    if (!(s_max < 1e6)) s_max = 1e6;
+    if (!with_shadow) s_max = 0;
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    for (int c = 0; c < 16; c++) {
+        const double s = c < 8 ? 0.0 : s_max;
+        double w[3];
+        for (int i = 0; i < 3; i++) w[i] = b.corner[c & 7][i] - s * A.light_dir[i] - A.cam_pos[i];
+        const double z = w[0] * A.cam_fwd[0] + w[1] * A.cam_fwd[1] + w[2] * A.cam_fwd[2];
+        if (!(z > 1e-4)) return false;
+        const double sx = (w[0] * A.cam_right[0] + w[1] * A.cam_right[1] + w[2] * A.cam_right[2]) / z;
+        const double sy = (w[0] * A.cam_up[0] + w[1] * A.cam_up[1] + w[2] * A.cam_up[2]) / z;
+        const double px = (sx / ((double)A.aspect * A.scale) + 1.0) * 0.5 * A.width - 0.5;     // inverse of camera.c:18
+        const double py = (1.0 - sy / (double)A.scale) * 0.5 * A.height - 0.5;                  // inverse of camera.c:19
+        if (!(px == px) || !(py == py)) return false;
+        lo[0] = px < lo[0] ? px : lo[0]; hi[0] = px > hi[0] ? px : hi[0];
+        lo[1] = py < lo[1] ? py : lo[1]; hi[1] = py > hi[1] ? py : hi[1];
+    }
+    const int tiles_x = (A.width + 7) / 8, tiles_y = (A.height + 7) / 8;
+    auto tile_lo = [](double v, int n) { const double t = floor((v - 2.0) / 8.0); return t < 0 ? 0 : (t > n ? n : (int)t); };
+    auto tile_hi = [](double v, int n) { const double t = floor((v + 2.0) / 8.0) + 1.0; return t < 0 ? 0 : (t > n ? n : (int)t); };
+    rect[0] = tile_lo(lo[0], tiles_x); rect[1] = tile_lo(lo[1], tiles_y);
+    rect[2] = tile_hi(hi[0], tiles_x); rect[3] = tile_hi(hi[1], tiles_y);
+    return true;
 }
 
 }  // namespace rt

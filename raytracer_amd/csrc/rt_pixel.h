@@ -8,13 +8,20 @@
 //  * Equal t: inside a leaf the lowest index wins (strict '<', bvh.c:95); between siblings the
 //    right child wins (bvh.c:113-124), i.e. the later leaf in index order.  The packer gives every
 //    triangle a priority that encodes exactly that order, so "t smaller, or t equal and priority
-//    higher" picks the reference's winner regardless of visiting order.
+//    higher" picks the reference's winner regardless of visiting order -- and regardless of how
+//    the visited set is divided among cooperating lanes.
 //  * Across meshes an earlier mesh wins ties (strict '<', scene.c:82).
 //  * The shadow pass only uses "any triangle accepted" (scene.c:133-138), so it may stop at the
 //    first accepted triangle.
 #pragma once
 #include "rt_exact.h"
 #include "rt_layout.h"
+
+#if defined(__HIPCC__) || defined(__clang__)
+#define RT_UNROLL _Pragma("unroll")
+#else
+#define RT_UNROLL _Pragma("GCC unroll 8")
+#endif
 
 namespace rt {
 
@@ -23,56 +30,150 @@ struct Hit {
     uint32_t tri;
     uint32_t prio;
 };
+RT_HD Hit no_hit() { Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; h.prio = 0; return h; }
 
 struct Work {
     uint32_t slabs, tris;
 };
 
-// Closest hit (ANY=false) or any hit (ANY=true) of one mesh, ray already in mesh space.
-// `bound` is the t the caller passes in (scene.c:74): the reference only honours it when the
-// root is a leaf (bvh.c:85); otherwise leaves start from 1e30f (bvh.c:106).
-// FULL=true keeps going after the first accepted triangle of an any-hit query, so that the
-// work counters equal the reference's (which always finishes the traversal).
-template <bool ANY, bool COUNT, bool FULL, class Stack>
-RT_HD bool trace_mesh(const MeshArgs& M, F3 o, F3 d, F3 inv, float bound, Hit& hit, Stack& stack, Work& work) {
+// Node source: where PairNodes are read from.  GlobalNodes reads the scene's combined node array
+// through the vector cache; the kernels also have a source that reads a copy staged in LDS.
+struct GlobalNodes {
+    const PairNode* all;
+    RT_HD const PairNode& operator()(const MeshArgs& M, uint32_t ref) const { return all[M.pair_base + ref]; }
+};
+
+// Distance culling (used unless the caller asks for the reference's visiting order).
+// A subtree is skipped when its box is entered farther away than the closest accepted hit.  Both
+// distances carry rounding error (the slab entry is within a few ulp of the true one; Moeller-
+// Trumbore's t is not as tight on slivers), so a box is only skipped when it starts beyond
+// best*(1 + 2^-9) + 2^-13: a triangle inside it would need a t that is wrong by 0.2 % to have won.
+// Ties (equal t) lie well inside the margin and are still visited, so the tie rule is unaffected.
+RT_HD float cull_limit(float best) { return best * 1.001953125f + 0.0001220703125f; }
+
+// True when hit a (if found) is the one the reference would keep over hit b.
+RT_HD bool beats(bool a_found, const Hit& a, bool b_found, const Hit& b) {
+    return a_found && (!b_found || a.t < b.t || (a.t == b.t && a.prio > b.prio));
+}
+
+constexpr uint32_t kLeafBatch = 4;       // triangles fetched together in a leaf
+
+// State of one closest-hit / any-hit query while it runs.
+struct Query {
+    float best_t;        // bvh.c:85 / bvh.c:106: bound of the leaf tests
+    float bound;         // the caller's closest_t (scene.c:74)
+    float limit;         // culling distance (only used when culling)
+    bool found;
+    Hit hit;
+};
+
+// Tests the triangles of one leaf (bvh.c:89-103).  Returns true when an any-hit query may stop.
+// Triangles are fetched kLeafBatch at a time before any of them is tested, so that a leaf pays
+// one memory round trip instead of one per triangle.
+template <bool ANY, bool COUNT, bool FULL>
+RT_HD bool test_leaf(const MeshArgs& M, uint32_t ref, F3 o, F3 d, Query& q, Work& work) {
+    constexpr bool CULL = !FULL && !ANY;
+    const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
+    for (uint32_t i0 = 0; i0 < count; i0 += kLeafBatch) {
+        TriRec T[kLeafBatch];                                  // registers: every index below is a constant
+        const uint32_t n = count - i0 < kLeafBatch ? count - i0 : kLeafBatch;
+        RT_UNROLL
+        for (uint32_t k = 0; k < kLeafBatch; k++) T[k] = M.tris[first + i0 + (k < n ? k : 0)];
+        RT_UNROLL
+        for (uint32_t k = 0; k < kLeafBatch; k++) {
+            if (k >= n) continue;
+            float t, u, v;
+            if (COUNT) work.tris++;
+            if (!moller_trumbore(o, d, f3(T[k].v0), f3(T[k].e1), f3(T[k].e2), t, u, v)) continue;
+            if (ANY) {
+                if (t < q.best_t) {
+                    q.found = true;
+                    if (!FULL) return true;
+                }
+            } else if (t < q.best_t || (q.found && t == q.best_t && T[k].prio > q.hit.prio)) {
+                q.best_t = t; q.found = true;
+                q.hit.t = t; q.hit.u = u; q.hit.v = v; q.hit.tri = first + i0 + k; q.hit.prio = T[k].prio;
+                if (CULL && t < q.bound) q.limit = cull_limit(t);
+            }
+        }
+    }
+    return false;
+}
+
+// Start of a query against one mesh: the root box test (bvh.c:82 at the root) and the bounds.
+// Returns false when the traversal has nothing to visit.
+template <bool ANY, bool COUNT, bool FULL>
+RT_HD bool begin_query(const MeshArgs& M, F3 o, F3 inv, float bound, Query& q, Work& work) {
+    constexpr bool CULL = !FULL && !ANY;
     if (COUNT) work.slabs++;
-    if (!slab(o, inv, M.root_min, M.root_max)) return false;           // bvh.c:82 at the root
+    float entry;
+    if (!slab_t(o, inv, M.root_min, M.root_max, entry)) return false;
     if (M.empty) return false;
-    const bool root_leaf = (M.root_ref & kLeafBit) != 0;
-    float best_t = root_leaf ? bound : 1e30f;
-    bool found = false;
+    // `bound` is the t the caller passes in: the reference only honours it inside a root that is
+    // a leaf (bvh.c:85); otherwise leaves start from 1e30f (bvh.c:106).  The caller accepts the
+    // result only if it is below `bound` (scene.c:82), so hits at or beyond it need not be found.
+    q.best_t = (M.root_ref & kLeafBit) ? bound : 1e30f;
+    q.bound = bound;
+    q.limit = cull_limit(bound);
+    q.found = false;
+    q.hit = no_hit();
+    return !(CULL && entry > q.limit);
+}
+
+// Closest hit (ANY=false) or any hit (ANY=true) of one mesh by ONE lane, ray already in mesh space.
+// FULL=true reproduces the reference's work exactly: every box whose ancestors' slabs all pass is
+// visited, and an any-hit query keeps going after its first accepted triangle.
+// FULL=false visits the nearer child first, skips boxes beyond the closest hit so far, and ends an
+// any-hit query at the first accepted triangle; the result is the same.
+template <bool ANY, bool COUNT, bool FULL, class Stack, class Nodes>
+RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& hit, Stack& stack, Work& work) {
+    constexpr bool CULL = !FULL && !ANY;
+    Query q;
+    if (!begin_query<ANY, COUNT, FULL>(M, o, inv, bound, q, work)) return false;
     stack.clear();
     stack.push(M.root_ref);
     while (!stack.empty()) {
         const uint32_t ref = stack.pop();
         if (ref & kLeafBit) {
-            const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
-            for (uint32_t i = 0; i < count; i++) {
-                const TriRec& T = M.tris[first + i];
-                float t, u, v;
-                if (COUNT) work.tris++;
-                if (!moller_trumbore(o, d, f3(T.v0), f3(T.e1), f3(T.e2), t, u, v)) continue;
-                if (ANY) {
-                    if (t < best_t) {
-                        if (!FULL) return true;
-                        found = true;
-                    }
-                } else if (t < best_t || (found && t == best_t && T.prio > hit.prio)) {
-                    best_t = t; found = true;
-                    hit.t = t; hit.u = u; hit.v = v; hit.tri = first + i; hit.prio = T.prio;
-                }
-            }
+            if (test_leaf<ANY, COUNT, FULL>(M, ref, o, d, q, work)) return true;
         } else {
-            const PairNode& N = M.pairs[ref];
+            const PairNode& N = nodes(M, ref);
             if (COUNT) work.slabs += 2;
-            const bool hl = slab(o, inv, N.lmin, N.lmax);
-            const bool hr = slab(o, inv, N.rmin, N.rmax);
-            if (hr) stack.push(N.rref);
-            if (hl) stack.push(N.lref);
+            float tl, tr;
+            bool hl = slab_t(o, inv, N.lmin, N.lmax, tl);
+            bool hr = slab_t(o, inv, N.rmin, N.rmax, tr);
+            if (CULL) {
+                hl = hl && !(tl > q.limit);
+                hr = hr && !(tr > q.limit);
+                const bool left_first = !(tr < tl);                    // nearer child is popped first
+                const uint32_t far_ref = left_first ? N.rref : N.lref, near_ref = left_first ? N.lref : N.rref;
+                const bool far_hit = left_first ? hr : hl, near_hit = left_first ? hl : hr;
+                if (far_hit) stack.push(far_ref);
+                if (near_hit) stack.push(near_ref);
+            } else {
+                if (hr) stack.push(N.rref);
+                if (hl) stack.push(N.lref);
+            }
         }
     }
-    return found;
+    hit = q.hit;
+    return q.found;
 }
+
+// ---- who traverses ------------------------------------------------------------------------
+// A "party" runs the traversal of one ray against one mesh.  Solo: the calling lane alone.  The
+// kernels add a party in which kGroupLanes adjacent lanes hold the same ray and share its stack.
+struct Solo {
+    template <bool COUNT, bool FULL, class Stack, class Nodes>
+    RT_HD bool closest(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& h, Stack& st, Work& w) const {
+        return trace_mesh<false, COUNT, FULL>(M, nodes, o, d, inv, bound, h, st, w);
+    }
+    template <bool COUNT, bool FULL, class Stack, class Nodes>
+    RT_HD bool any(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, Stack& st, Work& w) const {
+        Hit h = no_hit();
+        return trace_mesh<true, COUNT, FULL>(M, nodes, o, d, inv, 1e30f, h, st, w);
+    }
+};
 
 struct PixelOut {
     uint8_t r, g, b;
@@ -83,8 +184,8 @@ struct PixelOut {
     uint32_t dark;       // 0/1
 };
 
-template <bool COUNT, bool FULL, class Stack>
-RT_HD PixelOut shade_pixel(const FrameArgs& A, int px, int py, Stack& stack, Work& work) {
+template <bool COUNT, bool FULL, class Stack, class Nodes, class Party>
+RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& party, int px, int py, Stack& stack, Work& work) {
     PixelOut out;
     // ---- camera ray (camera.c:12-30; basis and tan() hoisted to the host) ----
     const float fx = ((float)px + 0.5f) / (float)A.width;             // scene.c:61
@@ -97,13 +198,13 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, int px, int py, Stack& stack, Wor
     // ---- closest hit over the meshes (scene.c:72-108) ----
     float closest = 1e30f;
     int who = -1;
-    Hit best; best.t = 0; best.u = 0; best.v = 0; best.tri = 0; best.prio = 0;
+    Hit best = no_hit();
     for (int m = 0; m < A.n_mesh; m++) {
         const MeshArgs& M = A.mesh[m];
         const F3 lo = f3(M.cam_o);                                     // ray.c:19 (same for every pixel)
         const F3 ld = unit(xform_vector<4>(M.inv, wd));                // ray.c:20,22
-        Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; h.prio = 0;
-        if (trace_mesh<false, COUNT, FULL>(M, lo, ld, recip(ld), closest, h, stack, work) && h.t < closest) {
+        Hit h = no_hit();
+        if (party.template closest<COUNT, FULL>(M, nodes, lo, ld, recip(ld), closest, h, stack, work) && h.t < closest) {
             closest = h.t; who = m; best = h;
         }
     }
@@ -140,8 +241,7 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, int px, int py, Stack& stack, Wor
     for (int m = 0; m < A.n_mesh && !dark; m++) {
         const MeshArgs& S = A.mesh[m];
         const F3 lo = xform_point(S.inv, S.wrow, so);                  // ray.c:19
-        Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; h.prio = 0;
-        dark = trace_mesh<true, COUNT, FULL>(S, lo, f3(S.lit_d), f3(S.lit_inv), 1e30f, h, stack, work);
+        dark = party.template any<COUNT, FULL>(S, nodes, lo, f3(S.lit_d), f3(S.lit_inv), stack, work);
     }
     float diffuse = 0.2f;                                              // scene.c:115
     const F3 L = f3(A.light_dir);

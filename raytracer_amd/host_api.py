@@ -90,6 +90,8 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `make product`")
+        from .capi import _load_torch_hip_first
+        _load_torch_hip_first()
         L = C.CDLL(LIB_PATH)
         L.create_scene.restype = Scene
         L.create_scene.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]

@@ -31,6 +31,7 @@ struct EmulMesh {
 };
 struct EmulScene {
     std::vector<EmulMesh> meshes;
+    std::vector<PairNode> all_pairs;
     std::string err;
     int stack_high = 0;
 };
@@ -52,6 +53,7 @@ int emul_mesh_add(void* sp, const rt_triangle* tris, int32_t n_tris, const rt_fl
     m.texels.resize((size_t)tw * th);
     memcpy(m.texels.data(), rgba, (size_t)tw * th * 4);
     m.tw = tw; m.th = th;
+    s->all_pairs.insert(s->all_pairs.end(), m.pk.pairs.begin(), m.pk.pairs.end());
     s->meshes.push_back(std::move(m));
     return RT_OK;
 }
@@ -88,20 +90,23 @@ void emul_placement(const rt_transform* tf, const rt_camera* cam, const rt_light
 
 int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_transform* tfs, int32_t n_tf,
                 int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_id, float* hit_t, uint8_t* shadow,
-                rt_counters* counters, int32_t full) {
+                rt_counters* counters, int32_t full, uint32_t* px_slabs, uint32_t* px_tris) {
     EmulScene* s = (EmulScene*)sp;
     if (n_tf != (int32_t)s->meshes.size() || n_tf > kMaxMeshes) { s->err = "transform count"; return RT_ERR_INVALID; }
     FrameArgs A; memset(&A, 0, sizeof A);
     fill_camera(*cam, *light, width, height, A);
     A.n_mesh = n_tf;
+    uint32_t base = 0;
     for (int m = 0; m < n_tf; m++) {
         MeshArgs& M = A.mesh[m];
         const EmulMesh& E = s->meshes[(size_t)m];
-        M.pairs = E.pk.pairs.data(); M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
+        M.pair_base = base; M.pair_count = (uint32_t)E.pk.pairs.size(); base += M.pair_count;
+        M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
         M.root_ref = E.pk.root_ref; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
         fill_placement(tfs[m], A, M);
     }
+    GlobalNodes nodes; nodes.all = s->all_pairs.data();
     unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
     int high = 0;
     #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_slab, c_tri, c_hit, c_dark) reduction(max : high)
@@ -109,12 +114,16 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         for (int x = 0; x < width; x++) {
             ArrayStack st;
             Work w; w.slabs = 0; w.tris = 0;
-            PixelOut r = full ? shade_pixel<true, true>(A, x, y, st, w) : shade_pixel<true, false>(A, x, y, st, w);
+            // full: 1 = reference visiting order; 0 = nearer child first with distance culling
+            PixelOut r = full ? shade_pixel<true, true>(A, nodes, Solo(), x, y, st, w)
+                              : shade_pixel<true, false>(A, nodes, Solo(), x, y, st, w);
             const size_t p = (size_t)y * width + x;
             rgb[p * 3] = r.r; rgb[p * 3 + 1] = r.g; rgb[p * 3 + 2] = r.b;
             if (hit_id) hit_id[p] = r.hit_id;
             if (hit_t) hit_t[p] = r.hit_t;
             if (shadow) shadow[p] = r.shadow;
+            if (px_slabs) px_slabs[p] = w.slabs;
+            if (px_tris) px_tris[p] = w.tris;
             c_slab += w.slabs; c_tri += w.tris; c_hit += r.hit; c_dark += r.dark;
             if (st.high > high) high = st.high;
         }
