@@ -18,6 +18,7 @@ namespace {
 
 struct DeviceMesh {
     std::vector<PairNode> pairs;   // host copy; the device copy lives in the scene's combined array
+    std::vector<TriRec> tris;      // host copy, for the LDS-resident blob
     int depth = 0;
     TriRec* d_tris = nullptr;
     AttrRec* d_attrs = nullptr;
@@ -36,10 +37,16 @@ struct rt_ctx {
     std::vector<DeviceMesh> meshes;
     PairNode* d_all_pairs = nullptr;         // PairNodes of all meshes, rebuilt when the mesh list changes
     uint32_t n_all_pairs = 0;
+    uint8_t* d_resident = nullptr;           // nodes + triangles of the small meshes, as the lean kernels stage them in LDS
+    uint32_t resident_bytes = 0;
     uint32_t stack_entries = 2;
     bool scene_dirty = true;
     TileQueue* d_queue = nullptr;
-    void* d_tile_clock = nullptr;            // caller-owned trace buffer (rt_set_trace_buffer)
+    DeferQueue* d_defer = nullptr;           // two-pass variant: counters ...
+    uint32_t* d_defer_items = nullptr;       // ... and the list of deferred pixels (one slot per pixel of the largest frame)
+    size_t defer_capacity = 0;
+    unsigned two_pass_frames = 0;            // selects the counter of the next two-pass frame
+    void* d_tile_clock = nullptr;           // caller-owned trace buffer (rt_set_trace_buffer)
     DeviceCounters* d_counters = nullptr;
     bool counters_pending = false;
     // planes used by rt_render_frame_host
@@ -47,6 +54,8 @@ struct rt_ctx {
     size_t plane_pixels = 0;
     LaunchConfig cfg;
     int timing = 1;
+    int budget = 48;               // two-pass variant: node visits per pixel before it is deferred
+    int resident_budget = (int)kResidentBudget;   // bytes of small meshes staged in LDS by the lean kernels
     int coop = 1;                  // cooperative rendering of the big meshes' screen area (variant 3)
     std::string err;
 };
@@ -105,6 +114,28 @@ int commit_scene(rt_ctx* ctx) {
     int st = upload_array(ctx, all, &ctx->d_all_pairs);
     if (st != RT_OK) return st;
     ctx->n_all_pairs = (uint32_t)all.size();
+    // LDS-resident blob: the smallest meshes first, while they fit in kResidentBudget bytes.
+    if (ctx->d_resident) (void)hipFree(ctx->d_resident);
+    ctx->d_resident = nullptr;
+    std::vector<uint8_t> blob;
+    std::vector<size_t> order(ctx->meshes.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    auto bytes_of = [&](size_t i) { return ctx->meshes[i].pairs.size() * sizeof(PairNode) + ((ctx->meshes[i].tris.size() * sizeof(TriRec) + 63) & ~(size_t)63); };
+    for (size_t i = 1; i < order.size(); i++)
+        for (size_t j = i; j > 0 && bytes_of(order[j]) < bytes_of(order[j - 1]); j--) std::swap(order[j], order[j - 1]);
+    for (auto& m : ctx->meshes) { m.proto.res_pairs = kNotResident; m.proto.res_tris = kNotResident; }
+    for (size_t k : order) {
+        DeviceMesh& m = ctx->meshes[k];
+        if (m.proto.empty || blob.size() + bytes_of(k) > (size_t)ctx->resident_budget) continue;
+        m.proto.res_pairs = (uint32_t)blob.size();
+        blob.insert(blob.end(), (const uint8_t*)m.pairs.data(), (const uint8_t*)(m.pairs.data() + m.pairs.size()));
+        m.proto.res_tris = (uint32_t)blob.size();
+        blob.insert(blob.end(), (const uint8_t*)m.tris.data(), (const uint8_t*)(m.tris.data() + m.tris.size()));
+        blob.resize((blob.size() + 63) & ~(size_t)63, 0);
+    }
+    st = upload_array(ctx, blob, &ctx->d_resident);
+    if (st != RT_OK) return st;
+    ctx->resident_bytes = (uint32_t)blob.size();
     ctx->stack_entries = (uint32_t)depth + 2;        // a chain of `depth` PairNodes holds at most depth+1 entries
     ctx->scene_dirty = false;
     return RT_OK;
@@ -160,6 +191,8 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, sizeof(DeviceCounters));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_queue, sizeof(TileQueue));
     if (e == hipSuccess) e = hipMemset(ctx->d_queue, 0, sizeof(TileQueue));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_defer, sizeof(DeferQueue));
+    if (e == hipSuccess) e = hipMemset(ctx->d_defer, 0, sizeof(DeferQueue));
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) { ctx->cfg.queue = ctx->d_queue; ctx->cfg.n_cus = cus > 0 ? cus : 256; }
@@ -178,7 +211,10 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& m : ctx->meshes) free_mesh(m);
     if (ctx->d_all_pairs) (void)hipFree(ctx->d_all_pairs);
+    if (ctx->d_resident) (void)hipFree(ctx->d_resident);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_defer) (void)hipFree(ctx->d_defer);
+    if (ctx->d_defer_items) (void)hipFree(ctx->d_defer_items);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
     if (ctx->d_id) (void)hipFree(ctx->d_id);
@@ -230,7 +266,7 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const r
     }
     if (st != RT_OK) { free_mesh(dm); return st; }
     memset(&dm.proto, 0, sizeof(dm.proto));
-    dm.pairs = pk.pairs; dm.depth = pk.depth;
+    dm.pairs = pk.pairs; dm.tris = pk.tris; dm.depth = pk.depth;
     dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs; dm.proto.texels = dm.d_texels;
     memcpy(dm.proto.root_min, pk.root_min, 12);
     memcpy(dm.proto.root_max, pk.root_max, 12);
@@ -280,6 +316,7 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
     if (cst != RT_OK) return cst;
     SceneArgs S;
     S.pairs = ctx->d_all_pairs; S.n_pairs = ctx->n_all_pairs; S.stack_entries = ctx->stack_entries;
+    S.resident = ctx->d_resident; S.resident_bytes = ctx->resident_bytes;
 
     FrameArgs A;
     memset(&A, 0, sizeof(A));
@@ -329,7 +366,29 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    RT_HIP(ctx, launch_render(A, S, O, ctx->cfg, s));
+    if (ctx->cfg.variant == 4 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER)) == 0) {
+        const size_t pixels = (size_t)width * (size_t)height;
+        if (pixels > ctx->defer_capacity) {
+            RT_HIP(ctx, hipDeviceSynchronize());          // an earlier frame may still be reading the old list
+            if (ctx->d_defer_items) (void)hipFree(ctx->d_defer_items);
+            ctx->d_defer_items = nullptr; ctx->defer_capacity = 0;
+            RT_HIP(ctx, hipMalloc((void**)&ctx->d_defer_items, pixels * sizeof(uint32_t)));
+            ctx->defer_capacity = pixels;
+        }
+        ctx->cfg.defer = ctx->d_defer;
+        ctx->cfg.defer_items = ctx->d_defer_items;
+        ctx->cfg.defer_capacity = (uint32_t)ctx->defer_capacity;
+        ctx->cfg.parity = (int)(ctx->two_pass_frames++ & 1u);
+        A.defer_budget = ctx->budget;
+    }
+    hipError_t le = launch_render(A, S, O, ctx->cfg, s);
+    if (le != hipSuccess) {
+        // leave the work-distribution words of the persistent / two-pass variants in their idle state
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(ctx->d_queue, 0, sizeof(TileQueue));
+        (void)hipMemset(ctx->d_defer, 0, sizeof(DeferQueue));
+        return hip_fail(ctx, le, "kernel launch");
+    }
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
     return RT_OK;
 }
@@ -402,6 +461,14 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     }
     if (!strcmp(name, "timing")) { ctx->timing = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "coop")) { ctx->coop = value; return RT_OK; }
+    if (!strcmp(name, "resident_budget")) {
+        if (value < 0 || value > (int)kResidentBudget) return fail(ctx, RT_ERR_INVALID, "resident_budget out of range");
+        ctx->resident_budget = value; ctx->scene_dirty = true; return RT_OK;
+    }
+    if (!strcmp(name, "budget")) {
+        if (value < 1) return fail(ctx, RT_ERR_INVALID, "budget must be positive");
+        ctx->budget = value; return RT_OK;
+    }
     return fail(ctx, RT_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -411,6 +478,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "block")) { *value = ctx->cfg.block; return RT_OK; }
     if (!strcmp(name, "timing")) { *value = ctx->timing; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
+    if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }
     if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }
     if (!strcmp(name, "default_variant")) { *value = kDefaultVariant; return RT_OK; }
     return RT_ERR_INVALID;

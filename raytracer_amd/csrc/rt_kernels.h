@@ -7,8 +7,8 @@
 
 namespace rt {
 
-constexpr int kNumVariants = 4;      // kernel variants selectable through LaunchConfig::variant
-constexpr int kDefaultVariant = 3;
+constexpr int kNumVariants = 10;     // kernel variants selectable through LaunchConfig::variant
+constexpr int kDefaultVariant = 4;
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 
 struct LaunchConfig {
@@ -16,6 +16,11 @@ struct LaunchConfig {
     int block = 256;                 // threads per workgroup (variant 0)
     int n_cus = 256;                 // compute units of the device (grid of the persistent variant)
     TileQueue* queue = nullptr;      // zero-initialised device words owned by the context
+    // two-pass variant: list of deferred pixels (y*width+x), its counters, and which counter this frame uses
+    DeferQueue* defer = nullptr;
+    uint32_t* defer_items = nullptr;
+    uint32_t defer_capacity = 0;
+    int parity = 0;
 };
 
 // True when the scene's nodes and the traversal stacks of one workgroup fit in LDS.

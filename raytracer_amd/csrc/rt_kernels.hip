@@ -37,6 +37,7 @@ struct LdsStack {
 struct LdsNodes {
     const PairNode* all;
     __device__ __forceinline__ const PairNode& operator()(const MeshArgs& M, uint32_t ref) const { return all[M.pair_base + ref]; }
+    __device__ __forceinline__ const TriRec& tri(const MeshArgs& M, uint32_t index) const { return M.tris[index]; }
 };
 
 // Pixel of (tile, lane): a wave owns an 8x8 tile, lanes row-major inside it, so the rays of a
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const 
     const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
     if (active) {
         Work work; work.slabs = 0; work.tris = 0;
-        const PixelOut r = shade_pixel<COUNT, FULL>(A, nodes, Solo(), px, py, stack, work);
+        const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work);
         store_pixel(O, A.width, px, py, r);
         tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
     }
@@ -120,6 +121,73 @@ static hipError_t launch_direct(const FrameArgs& A, const SceneArgs& S, const Ou
     else if (count)     hipLaunchKernelGGL((render_direct<BLOCK, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     else if (full)      hipLaunchKernelGGL((render_direct<BLOCK, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     else                hipLaunchKernelGGL((render_direct<BLOCK, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Variants 5..9: variant 0 tuned for occupancy.  Frames are independent, so a caller that renders
+// an animation can keep several frames in flight on different streams; the frame rate is then
+// set by how many waves the chip holds and how long each one runs, not by the slowest tile.
+// DEPTH = stack entries per lane (16 covers trees up to depth 14: 4 KB of LDS per wave instead
+// of 8), LB = triangles fetched per leaf batch (12 VGPRs each), MINW = waves per SIMD the
+// register allocation has to admit.
+// ------------------------------------------------------------------------------------------
+// Geometry source of the lean kernels: meshes marked resident are read from the workgroup's LDS
+// copy, the others through the vector cache.  The mesh is the same for all lanes of a wave at any
+// time, so the choice never diverges.
+struct HybridNodes {
+    const PairNode* global_all;
+    const uint8_t* lds;          // the resident blob in LDS
+    __device__ __forceinline__ PairNode operator()(const MeshArgs& M, uint32_t ref) const {
+        if (M.res_pairs != kNotResident) return *reinterpret_cast<const PairNode*>(lds + M.res_pairs + (size_t)ref * sizeof(PairNode));
+        return global_all[M.pair_base + ref];
+    }
+    __device__ __forceinline__ TriRec tri(const MeshArgs& M, uint32_t index) const {
+        if (M.res_tris != kNotResident) return *reinterpret_cast<const TriRec*>(lds + M.res_tris + (size_t)index * sizeof(TriRec));
+        return M.tris[index];
+    }
+};
+
+template <int BLOCK, int DEPTH, uint32_t LB, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) render_lean(const FrameArgs A, const SceneArgs S, const OutputPlanes O) {
+    // [ stacks: DEPTH x BLOCK dwords ][ resident blob: S.resident_bytes ]
+    extern __shared__ uint4 lds_dyn[];
+    uint32_t* lds_stack = reinterpret_cast<uint32_t*>(lds_dyn);
+    uint4* lds_blob = lds_dyn + (DEPTH * BLOCK) / 4;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(S.resident);
+        const int n16 = (int)(S.resident_bytes / 16);
+        for (int i = threadIdx.x; i < n16; i += BLOCK) lds_blob[i] = src[i];
+        __syncthreads();
+    }
+    LdsStack<BLOCK> stack;
+    stack.base = &lds_stack[threadIdx.x];
+    stack.sp = 0;
+    HybridNodes nodes; nodes.global_all = S.pairs; nodes.lds = reinterpret_cast<const uint8_t*>(lds_blob);
+    const int tiles_x = (A.width + 7) >> 3;
+    const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    int px, py;
+    tile_pixel(tile, threadIdx.x & 63, tiles_x, px, py);
+    const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
+    if (px < A.width && py < A.height) {
+        Work work; work.slabs = 0; work.tris = 0;
+        const PixelOut r = shade_pixel<false, false, false>(A, nodes, SoloT<LB>(), px, py, stack, work);
+        store_pixel(O, A.width, px, py, r);
+    }
+    if (O.tile_clock && (threadIdx.x & 63) == 0 && tile < tiles_x * ((A.height + 7) >> 3)) {
+        O.tile_clock[2 * (size_t)tile] = t_start;
+        O.tile_clock[2 * (size_t)tile + 1] = wall_clock64();
+    }
+}
+
+template <int BLOCK, int DEPTH, uint32_t LB, int MINW>
+static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, hipStream_t stream) {
+    const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
+    const int waves_per_block = BLOCK / 64;
+    const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
+    const size_t lds = (size_t)DEPTH * BLOCK * sizeof(uint32_t) + S.resident_bytes;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;       // kResidentBudget keeps it below the default limit
+    hipLaunchKernelGGL((render_lean<BLOCK, DEPTH, LB, MINW>), dim3(blocks), dim3(BLOCK), lds, stream, A, S, O);
     return hipGetLastError();
 }
 
@@ -175,7 +243,7 @@ struct CoopGroup {
                 if (!__any(n_leaf > 0)) break;                          // nothing pending in any group of the wave
                 const int take = n_leaf < kGroupLanes ? n_leaf : kGroupLanes;
                 bool stop = false;
-                if ((int)j < take) stop = test_leaf<ANY, false, false>(M, leaf_slot(n_leaf - 1 - (int)j), o, d, q, unused);
+                if ((int)j < take) stop = test_leaf<ANY, false, false, kLeafBatch>(M, nodes, leaf_slot(n_leaf - 1 - (int)j), o, d, q, unused);
                 n_leaf -= take;
                 if (ANY) {
                     if (group_bits(__ballot(stop)) != 0) { done = true; n_leaf = 0; n_pair = 0; }
@@ -196,7 +264,7 @@ struct CoopGroup {
                 bool pl = false, pr = false, ll = false, lr = false;
                 uint32_t lref = 0, rref = 0;
                 if ((int)j < take) {
-                    const PairNode& N = nodes(M, pair_slot(n_pair - 1 - (int)j));
+                    const PairNode N = nodes(M, pair_slot(n_pair - 1 - (int)j));
                     float tl, tr;
                     bool hl = slab_t(o, inv, N.lmin, N.lmax, tl);
                     bool hr = slab_t(o, inv, N.rmin, N.rmax, tr);
@@ -244,6 +312,7 @@ struct CoopGroup {
         Hit h = no_hit();
         return run<true>(M, nodes, o, d, inv, 1e30f, h);
     }
+    __device__ __forceinline__ bool exhausted() const { return false; }
 };
 
 __device__ __forceinline__ bool in_rect(const int32_t* r, int tx, int ty) { return tx >= r[0] && tx < r[2] && ty >= r[1] && ty < r[3]; }
@@ -290,7 +359,7 @@ __global__ void __launch_bounds__(BLOCK) render_tiles(const FrameArgs A, const S
             party.area = &lds_stack[threadIdx.x & ~7u];
             LdsStack<BLOCK> unused_stack; unused_stack.base = nullptr; unused_stack.sp = 0;
             Work work; work.slabs = 0; work.tris = 0;
-            const PixelOut r = shade_pixel<false, false>(A, nodes, party, px, py, unused_stack, work);
+            const PixelOut r = shade_pixel<false, false, false>(A, nodes, party, px, py, unused_stack, work);
             if ((lane & 7) == 0) store_pixel(O, A.width, px, py, r);
         }
     } else {
@@ -304,7 +373,7 @@ __global__ void __launch_bounds__(BLOCK) render_tiles(const FrameArgs A, const S
             stack.base = &lds_stack[threadIdx.x];
             stack.sp = 0;
             Work work; work.slabs = 0; work.tris = 0;
-            const PixelOut r = shade_pixel<COUNT, FULL>(A, nodes, Solo(), px, py, stack, work);
+            const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work);
             store_pixel(O, A.width, px, py, r);
             tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
         }
@@ -331,6 +400,106 @@ static hipError_t launch_tiles(const FrameArgs& A, const SceneArgs& S, const Out
     else if (count)     hipLaunchKernelGGL((render_tiles<BLOCK, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     else if (full)      hipLaunchKernelGGL((render_tiles<BLOCK, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     else                hipLaunchKernelGGL((render_tiles<BLOCK, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Variant 4: two passes.  Pass 1 renders every tile with one lane per pixel, except that a pixel
+// whose rays together need more than FrameArgs::defer_budget node visits is abandoned and appended to a list
+// (ray compaction: ballot + popcount offsets inside the wave, one LDS add per wave, one global
+// add per workgroup).  Pass 2 walks the list with cooperative groups, eight pixels per wave.
+// Only the pixels that need the wide traversal pay for it, and none of them holds up a tile.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) render_pass1(const FrameArgs A, const SceneArgs S, const OutputPlanes O,
+                                                      DeferQueue* dq, uint32_t* items, const uint32_t capacity, const int parity) {
+    __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
+    __shared__ uint32_t block_count, block_base;
+    if (threadIdx.x == 0) block_count = 0;
+    __syncthreads();
+
+    LdsStack<BLOCK> stack;
+    stack.base = &lds_stack[threadIdx.x];
+    stack.sp = 0;
+    GlobalNodes nodes; nodes.all = S.pairs;
+
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (A.width + 7) >> 3, tiles_y = (A.height + 7) >> 3;
+    const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
+    bool defer = false;
+    int px = 0, py = 0;
+    if (tile < tiles_x * tiles_y) {
+        tile_pixel(tile, lane, tiles_x, px, py);
+        if (px < A.width && py < A.height) {
+            Work work; work.slabs = 0; work.tris = 0;
+            SoloBudget party; party.steps = A.defer_budget;
+            const PixelOut r = shade_pixel<false, false, true>(A, nodes, party, px, py, stack, work);
+            defer = r.deferred != 0;
+            if (!defer) store_pixel(O, A.width, px, py, r);
+        }
+        if (O.tile_clock && lane == 0) {
+            O.tile_clock[2 * (size_t)tile] = t_start;
+            O.tile_clock[2 * (size_t)tile + 1] = wall_clock64();
+        }
+    }
+    // compaction of the deferred pixels of this workgroup into the list
+    const unsigned long long votes = __ballot(defer);
+    const uint32_t n_wave = (uint32_t)__popcll(votes);
+    uint32_t wave_off = 0;
+    if (lane == 0 && n_wave) wave_off = atomicAdd(&block_count, n_wave);
+    wave_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_off);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_count) block_base = atomicAdd(&dq->count[parity], block_count);
+    __syncthreads();
+    if (defer) {
+        const uint32_t at = block_base + wave_off + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+        if (at < capacity) items[at] = (uint32_t)py * (uint32_t)A.width + (uint32_t)px;
+    }
+}
+
+constexpr int kPass2Block = 256;
+
+__global__ void __launch_bounds__(kPass2Block) render_pass2(const FrameArgs A, const SceneArgs S, const OutputPlanes O,
+                                                            DeferQueue* dq, const uint32_t* items, const uint32_t capacity, const int parity) {
+    __shared__ uint32_t lds_stack[kStackDepth * kPass2Block];
+    GlobalNodes nodes; nodes.all = S.pairs;
+    const int lane = threadIdx.x & 63;
+    uint32_t n = dq->count[parity];
+    if (n > capacity) n = capacity;
+    const uint32_t n_batches = (n + kGroupLanes - 1) / kGroupLanes;
+    const uint32_t wave = blockIdx.x * (kPass2Block / 64) + (threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * (kPass2Block / 64);
+    if (wave == 0 && lane == 0) dq->count[parity ^ 1] = 0;           // the next frame's counter
+    CoopGroup<kPass2Block> party;
+    party.lane = (uint32_t)lane;
+    party.area = &lds_stack[threadIdx.x & ~7u];
+    LdsStack<kPass2Block> unused_stack; unused_stack.base = nullptr; unused_stack.sp = 0;
+    for (uint32_t b = wave; b < n_batches; b += total_waves) {     // b is uniform over the wave
+        const uint32_t at = b * kGroupLanes + (uint32_t)(lane >> 3);
+        if (at < n) {
+            const uint32_t id = items[at];
+            const int py = (int)(id / (uint32_t)A.width), px = (int)(id - (uint32_t)py * (uint32_t)A.width);
+            Work work; work.slabs = 0; work.tris = 0;
+            const PixelOut r = shade_pixel<false, false, false>(A, nodes, party, px, py, unused_stack, work);
+            if ((lane & 7) == 0) store_pixel(O, A.width, px, py, r);
+        }
+    }
+}
+
+template <int BLOCK>
+static hipError_t launch_two_pass(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, const LaunchConfig& cfg, hipStream_t stream) {
+    const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
+    const int waves_per_block = BLOCK / 64;
+    const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
+    hipLaunchKernelGGL((render_pass1<BLOCK>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O, cfg.defer, cfg.defer_items,
+                       cfg.defer_capacity, cfg.parity);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // LDS (32 KB per workgroup) admits five workgroups of pass 2 per CU.
+    const int grid2 = (cfg.n_cus > 0 ? cfg.n_cus : 256) * 5;
+    hipLaunchKernelGGL(render_pass2, dim3(grid2), dim3(kPass2Block), 0, stream, A, S, O, cfg.defer, cfg.defer_items,
+                       cfg.defer_capacity, cfg.parity);
     return hipGetLastError();
 }
 
@@ -371,7 +540,7 @@ __global__ void __launch_bounds__(kResidentBlock) render_resident(const FrameArg
         const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
         if (px < A.width && py < A.height) {
             Work work; work.slabs = 0; work.tris = 0;
-            const PixelOut r = shade_pixel<COUNT, FULL>(A, nodes, Solo(), px, py, stack, work);
+            const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work);
             store_pixel(O, A.width, px, py, r);
             if (COUNT) { tot.pixels += 1; tot.hits += r.hit; tot.darks += r.dark; tot.slabs += work.slabs; tot.tris += work.tris; }
         }
@@ -448,7 +617,26 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
     int variant = cfg.variant;
     if ((variant == 1 || variant == 2) && (!cfg.queue || !resident_fits(S))) variant = 0;     // scene too large for LDS
     if (variant != 3 && A.n_rects != 0) return hipErrorInvalidValue;
+    // Work counts and the reference's visiting order are defined for one lane per ray.
+    if (variant == 4 && (count || full)) variant = 0;
+    // The lean variants exist for the plain frame only, and their short stack for shallow trees only.
+    if (variant >= 5 && (count || full || S.stack_entries > 16)) variant = 0;
+    if (variant >= 5) {
+        const int b = cfg.block;
+        switch (variant) {
+            case 5: return b == 64 ? launch_lean<64, 16, 2, 1>(A, S, O, stream) : launch_lean<256, 16, 2, 1>(A, S, O, stream);
+            case 6: return b == 64 ? launch_lean<64, 16, 1, 1>(A, S, O, stream) : launch_lean<256, 16, 1, 1>(A, S, O, stream);
+            case 7: return b == 64 ? launch_lean<64, 16, 2, 2>(A, S, O, stream) : launch_lean<256, 16, 2, 8>(A, S, O, stream);
+            case 8: return b == 64 ? launch_lean<64, 16, 4, 1>(A, S, O, stream) : launch_lean<256, 16, 4, 1>(A, S, O, stream);
+            default: return b == 64 ? launch_lean<64, 16, 1, 2>(A, S, O, stream) : launch_lean<256, 16, 1, 8>(A, S, O, stream);
+        }
+    }
+    if (variant == 4 && (!cfg.defer || !cfg.defer_items || (long long)cfg.defer_capacity < (long long)A.width * A.height)) return hipErrorInvalidValue;
     switch (variant) {
+        case 4:
+            if (cfg.block == 64) return launch_two_pass<64>(A, S, O, cfg, stream);
+            if (cfg.block == 128) return launch_two_pass<128>(A, S, O, cfg, stream);
+            return launch_two_pass<256>(A, S, O, cfg, stream);
         case 1:
             return launch_resident<0>(A, S, O, cfg, count, full, stream);
         case 2:

@@ -76,8 +76,15 @@ struct MeshArgs {
     float lit_d[3];              // normalised light direction in mesh space
     float lit_inv[3];            // 1.0f / lit_d
     uint32_t w_mode;             // 0: general w; 1: w == wrow[3] for every finite point; 2: w == 1.0f
+    // Byte offsets of this mesh's PairNodes / TriRecs inside the scene's LDS-resident blob
+    // (SceneArgs::resident), or kNotResident when the mesh is only in HBM.
+    uint32_t res_pairs, res_tris;
     uint32_t pad;
 };
+constexpr uint32_t kNotResident = 0xFFFFFFFFu;
+// Small meshes (nodes + triangles) are copied into LDS by every workgroup of the lean kernels, the
+// smallest first, as long as they fit in this many bytes.
+constexpr uint32_t kResidentBudget = 32 * 1024;
 
 struct FrameArgs {
     int32_t width, height;
@@ -93,6 +100,9 @@ struct FrameArgs {
     // cover the screen area where a ray, primary or shadow, can meet a big mesh.
     int32_t n_rects;
     int32_t rect[kMaxCoopRects][4];
+    // Two-pass variant: node visits one lane may spend on a pixel before handing it to the
+    // cooperative pass.
+    int32_t defer_budget;
     MeshArgs mesh[kMaxMeshes];
 };
 
@@ -105,6 +115,8 @@ struct SceneArgs {
     const PairNode* pairs;       // PairNodes of all meshes, mesh after mesh
     uint32_t n_pairs;
     uint32_t stack_entries;      // traversal stack entries per lane that the deepest mesh needs
+    const uint8_t* resident;     // blob of the LDS-resident meshes: per mesh its PairNodes, then its TriRecs
+    uint32_t resident_bytes;     // multiple of 64
 };
 
 // Work distribution state of the persistent kernels: tiles are handed out by an atomic counter;
@@ -112,6 +124,13 @@ struct SceneArgs {
 struct TileQueue {
     unsigned int next;
     unsigned int done;
+};
+
+// Two-pass rendering: pixels whose rays enter a big mesh are put on a list by the first pass and
+// rendered cooperatively by the second.  Frames alternate between the two counters; the second
+// pass of a frame clears the counter the next frame will use.
+struct DeferQueue {
+    unsigned int count[2];
 };
 
 struct OutputPlanes {

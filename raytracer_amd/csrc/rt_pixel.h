@@ -41,6 +41,7 @@ struct Work {
 struct GlobalNodes {
     const PairNode* all;
     RT_HD const PairNode& operator()(const MeshArgs& M, uint32_t ref) const { return all[M.pair_base + ref]; }
+    RT_HD const TriRec& tri(const MeshArgs& M, uint32_t index) const { return M.tris[index]; }
 };
 
 // Distance culling (used unless the caller asks for the reference's visiting order).
@@ -68,19 +69,19 @@ struct Query {
 };
 
 // Tests the triangles of one leaf (bvh.c:89-103).  Returns true when an any-hit query may stop.
-// Triangles are fetched kLeafBatch at a time before any of them is tested, so that a leaf pays
-// one memory round trip instead of one per triangle.
-template <bool ANY, bool COUNT, bool FULL>
-RT_HD bool test_leaf(const MeshArgs& M, uint32_t ref, F3 o, F3 d, Query& q, Work& work) {
+// Triangles are fetched LB at a time before any of them is tested, so that a leaf pays one
+// memory round trip per batch instead of one per triangle (at 12 registers per triangle held).
+template <bool ANY, bool COUNT, bool FULL, uint32_t LB, class Nodes>
+RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, F3 d, Query& q, Work& work) {
     constexpr bool CULL = !FULL && !ANY;
     const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
-    for (uint32_t i0 = 0; i0 < count; i0 += kLeafBatch) {
-        TriRec T[kLeafBatch];                                  // registers: every index below is a constant
-        const uint32_t n = count - i0 < kLeafBatch ? count - i0 : kLeafBatch;
+    for (uint32_t i0 = 0; i0 < count; i0 += LB) {
+        TriRec T[LB];                                          // registers: every index below is a constant
+        const uint32_t n = count - i0 < LB ? count - i0 : LB;
         RT_UNROLL
-        for (uint32_t k = 0; k < kLeafBatch; k++) T[k] = M.tris[first + i0 + (k < n ? k : 0)];
+        for (uint32_t k = 0; k < LB; k++) T[k] = nodes.tri(M, first + i0 + (k < n ? k : 0));
         RT_UNROLL
-        for (uint32_t k = 0; k < kLeafBatch; k++) {
+        for (uint32_t k = 0; k < LB; k++) {
             if (k >= n) continue;
             float t, u, v;
             if (COUNT) work.tris++;
@@ -125,19 +126,23 @@ RT_HD bool begin_query(const MeshArgs& M, F3 o, F3 inv, float bound, Query& q, W
 // visited, and an any-hit query keeps going after its first accepted triangle.
 // FULL=false visits the nearer child first, skips boxes beyond the closest hit so far, and ends an
 // any-hit query at the first accepted triangle; the result is the same.
-template <bool ANY, bool COUNT, bool FULL, class Stack, class Nodes>
-RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& hit, Stack& stack, Work& work) {
+// BUDGET=true counts the nodes taken off the stack against `steps`; when it runs out the query is
+// abandoned (returns false with steps < 0) and the caller hands the pixel to the cooperative pass.
+template <bool ANY, bool COUNT, bool FULL, bool BUDGET, uint32_t LB, class Stack, class Nodes>
+RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& hit, Stack& stack, Work& work,
+                      int& steps) {
     constexpr bool CULL = !FULL && !ANY;
     Query q;
     if (!begin_query<ANY, COUNT, FULL>(M, o, inv, bound, q, work)) return false;
     stack.clear();
     stack.push(M.root_ref);
     while (!stack.empty()) {
+        if (BUDGET && --steps < 0) return false;
         const uint32_t ref = stack.pop();
         if (ref & kLeafBit) {
-            if (test_leaf<ANY, COUNT, FULL>(M, ref, o, d, q, work)) return true;
+            if (test_leaf<ANY, COUNT, FULL, LB>(M, nodes, ref, o, d, q, work)) return true;
         } else {
-            const PairNode& N = nodes(M, ref);
+            const PairNode N = nodes(M, ref);
             if (COUNT) work.slabs += 2;
             float tl, tr;
             bool hl = slab_t(o, inv, N.lmin, N.lmax, tl);
@@ -163,16 +168,37 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
 // ---- who traverses ------------------------------------------------------------------------
 // A "party" runs the traversal of one ray against one mesh.  Solo: the calling lane alone.  The
 // kernels add a party in which kGroupLanes adjacent lanes hold the same ray and share its stack.
-struct Solo {
+template <uint32_t LB>
+struct SoloT {
     template <bool COUNT, bool FULL, class Stack, class Nodes>
     RT_HD bool closest(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& h, Stack& st, Work& w) const {
-        return trace_mesh<false, COUNT, FULL>(M, nodes, o, d, inv, bound, h, st, w);
+        int unused = 0;
+        return trace_mesh<false, COUNT, FULL, false, LB>(M, nodes, o, d, inv, bound, h, st, w, unused);
     }
     template <bool COUNT, bool FULL, class Stack, class Nodes>
     RT_HD bool any(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, Stack& st, Work& w) const {
         Hit h = no_hit();
-        return trace_mesh<true, COUNT, FULL>(M, nodes, o, d, inv, 1e30f, h, st, w);
+        int unused = 0;
+        return trace_mesh<true, COUNT, FULL, false, LB>(M, nodes, o, d, inv, 1e30f, h, st, w, unused);
     }
+    RT_HD bool exhausted() const { return false; }
+};
+using Solo = SoloT<kLeafBatch>;
+
+// One lane alone, but only for as long as the pixel stays cheap: all queries of the pixel draw on
+// one budget of node visits.
+struct SoloBudget {
+    mutable int steps;
+    template <bool COUNT, bool FULL, class Stack, class Nodes>
+    RT_HD bool closest(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& h, Stack& st, Work& w) const {
+        return trace_mesh<false, COUNT, FULL, true, kLeafBatch>(M, nodes, o, d, inv, bound, h, st, w, steps);
+    }
+    template <bool COUNT, bool FULL, class Stack, class Nodes>
+    RT_HD bool any(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, Stack& st, Work& w) const {
+        Hit h = no_hit();
+        return trace_mesh<true, COUNT, FULL, true, kLeafBatch>(M, nodes, o, d, inv, 1e30f, h, st, w, steps);
+    }
+    RT_HD bool exhausted() const { return steps < 0; }
 };
 
 struct PixelOut {
@@ -182,11 +208,15 @@ struct PixelOut {
     float hit_t;
     uint32_t hit;        // 0/1
     uint32_t dark;       // 0/1
+    uint32_t deferred;   // 1: not rendered, the party ran out of budget (DEFER only)
 };
 
-template <bool COUNT, bool FULL, class Stack, class Nodes, class Party>
+// DEFER=true gives up as soon as the party reports that its budget is exhausted and returns with
+// `deferred` set; nothing of such a pixel is stored.
+template <bool COUNT, bool FULL, bool DEFER, class Stack, class Nodes, class Party>
 RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& party, int px, int py, Stack& stack, Work& work) {
     PixelOut out;
+    out.deferred = 0;
     // ---- camera ray (camera.c:12-30; basis and tan() hoisted to the host) ----
     const float fx = ((float)px + 0.5f) / (float)A.width;             // scene.c:61
     const float fy = ((float)py + 0.5f) / (float)A.height;            // scene.c:62
@@ -207,6 +237,7 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
         if (party.template closest<COUNT, FULL>(M, nodes, lo, ld, recip(ld), closest, h, stack, work) && h.t < closest) {
             closest = h.t; who = m; best = h;
         }
+        if (DEFER && party.exhausted()) { out.deferred = 1; return out; }
     }
     out.hit_t = closest;
     if (who < 0) {                                                     // scene.c:156
@@ -242,6 +273,7 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
         const MeshArgs& S = A.mesh[m];
         const F3 lo = xform_point(S.inv, S.wrow, so);                  // ray.c:19
         dark = party.template any<COUNT, FULL>(S, nodes, lo, f3(S.lit_d), f3(S.lit_inv), stack, work);
+        if (DEFER && party.exhausted()) { out.deferred = 1; return out; }
     }
     float diffuse = 0.2f;                                              // scene.c:115
     const F3 L = f3(A.light_dir);

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Times kernel variants against each other in ONE process, interleaved over several rounds
-(kernel time from HIP events on the launch stream), and checks that every variant produces the
-same bytes as the first one.
+"""Times kernel variants against each other in ONE process, interleaved over several rounds, and
+checks that every variant produces the same bytes as the first one.
 
-    python scripts/sweep.py --configs 0:256,0:64,1:1024 --rounds 5 --frames 0,45 --out gpurun_out/sweep.json
+A config is variant:block[:budget[:streams]].  With streams > 1 consecutive frames are launched
+round-robin on that many HIP streams (frames are independent, so they may overlap on the GPU);
+the time reported is wall time of `reps` frames divided by `reps`, bracketed by device syncs.
+
+    python scripts/sweep.py --configs 0:256,0:256:48:4,4:256:32 --rounds 5 --frames 0,45 --out gpurun_out/sweep.json
 """
 import argparse
 import json
 import os
 import sys
+import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -24,7 +28,7 @@ def main():
     p.add_argument("--frames", default="0,45")
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--reps", type=int, default=8)
+    p.add_argument("--reps", type=int, default=16)
     p.add_argument("--out", default="gpurun_out/sweep.json")
     a = p.parse_args()
     from raytracer_amd import demo
@@ -33,15 +37,16 @@ def main():
     scene = demo.DemoScene(0)
     ctx = scene.ctx
     ctx.set_option("timing", 0)
-    stream = torch.cuda.Stream(device=dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
     frames = [int(f) for f in a.frames.split(",")]
     configs = []
     for c in a.configs.split(","):
         parts = [int(x) for x in c.split(":")]
-        configs.append((parts[0], parts[1], parts[2] if len(parts) > 2 else 1))
+        configs.append((parts[0], parts[1], parts[2] if len(parts) > 2 else 48, parts[3] if len(parts) > 3 else 1,
+                        parts[4] if len(parts) > 4 else 32))
     W, H = a.width, a.height
     ref = {}
-    buf = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    bufs = [torch.empty((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(8)]
     times = {c: {f: [] for f in frames} for c in configs}
     same = {c: True for c in configs}
     for r in range(a.rounds + 1):                         # round 0 = warm-up + parity check
@@ -49,30 +54,30 @@ def main():
             try:
                 ctx.set_option("variant", c[0])
                 ctx.set_option("block", c[1])
-                ctx.set_option("coop", c[2])
+                ctx.set_option("budget", c[2])
+                ctx.set_option("resident_budget", c[4] * 1024)
             except Exception as e:                        # unknown variant/block: skip
                 same[c] = f"unsupported: {e}"
                 continue
+            ns = c[3]
             for f in frames:
                 if r == 0:
-                    scene.render(f, W, H, buf, stream=stream.cuda_stream)
-                    stream.synchronize()
+                    scene.render(f, W, H, bufs[0], stream=streams[0].cuda_stream)
+                    torch.cuda.synchronize(dev)
                     if f not in ref:
-                        ref[f] = buf.clone()
-                    elif not torch.equal(ref[f], buf):
+                        ref[f] = bufs[0].clone()
+                    elif not torch.equal(ref[f], bufs[0]):
                         same[c] = False
                 else:
-                    # a.reps back-to-back launches between two events on the launch stream
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(stream)
-                    for _ in range(a.reps):
-                        scene.render(f, W, H, buf, stream=stream.cuda_stream)
-                    e1.record(stream)
-                    e1.synchronize()
-                    times[c][f].append(e0.elapsed_time(e1) / a.reps)
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for k in range(a.reps):
+                        scene.render(f, W, H, bufs[k % ns], stream=streams[k % ns].cuda_stream)
+                    torch.cuda.synchronize(dev)
+                    times[c][f].append((time.perf_counter() - t0) * 1e3 / a.reps)
     out = []
     for c in configs:
-        row = {"variant": c[0], "block": c[1], "coop": c[2], "same_bytes_as_first": same[c]}
+        row = {"variant": c[0], "block": c[1], "budget": c[2], "streams": c[3], "resident_kb": c[4], "same_bytes_as_first": same[c]}
         for f in frames:
             t = times[c][f]
             if t:

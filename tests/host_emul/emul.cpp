@@ -115,8 +115,8 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
             ArrayStack st;
             Work w; w.slabs = 0; w.tris = 0;
             // full: 1 = reference visiting order; 0 = nearer child first with distance culling
-            PixelOut r = full ? shade_pixel<true, true>(A, nodes, Solo(), x, y, st, w)
-                              : shade_pixel<true, false>(A, nodes, Solo(), x, y, st, w);
+            PixelOut r = full ? shade_pixel<true, true, false>(A, nodes, Solo(), x, y, st, w)
+                              : shade_pixel<true, false, false>(A, nodes, Solo(), x, y, st, w);
             const size_t p = (size_t)y * width + x;
             rgb[p * 3] = r.r; rgb[p * 3 + 1] = r.g; rgb[p * 3 + 2] = r.b;
             if (hit_id) hit_id[p] = r.hit_id;
