@@ -5,9 +5,11 @@ ground scene at 1920x1080, one ray per pixel plus one shadow ray per hit pixel.
     python bench.py --gpus N --steps K --warmup W
 
 A step is one frame.  Rank r of N renders frames r, r+N, r+2N, ... of the 96-frame animation
-(per-GPU work is fixed as N grows: weak scaling); for N > 1 the finished RGB8 framebuffers are
-gathered to rank 0 over RCCL inside the timed region, in batches that travel while the next
-batch renders.  Framebuffers stay in HBM; nothing is copied to the host inside the timed region.
+(per-GPU work is fixed as N grows: weak scaling).  Frames are submitted `--batch` at a time
+through rt_render_frames (one launch per batch: the long-running tiles of every frame in the batch
+overlap with the bulk of the others); for N > 1 each finished batch of RGB8 framebuffers is
+gathered to rank 0 over RCCL inside the timed region while the next batch renders.  Framebuffers
+stay in HBM; nothing is copied to the host inside the timed region.
 
 A ray is one camera ray or one shadow ray tested against the whole scene (all meshes):
 rays per frame = pixels + pixels that hit something.
@@ -47,8 +49,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=8)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--batch", type=int, default=4, help="frames per gather message (N > 1)")
-    p.add_argument("--variant", type=int, default=-1)
+    p.add_argument("--batch", type=int, default=8, help="frames per launch (and per gather message for N > 1)")
     p.add_argument("--block", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=8)
@@ -102,8 +103,6 @@ def main():
     from raytracer_amd import demo, sharding
     scene = demo.DemoScene(local)
     ctx = scene.ctx
-    if a.variant >= 0:
-        ctx.set_option("variant", a.variant)
     if a.block:
         ctx.set_option("block", a.block)
     W, H = a.width, a.height
@@ -121,20 +120,24 @@ def main():
     # ---- untimed: rays and reference-equivalent work of every distinct frame of this rank
     hit_id = torch.empty((H, W), dtype=torch.int32, device=dev)
     scratch = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-    info = {}
+    info, own = {}, {}
     from raytracer_amd import capi
     for f in sorted(set(seq[a.warmup:])):
         scene.render(f, W, H, scratch, hit_id=hit_id, flags=capi.RT_FLAG_COUNT_WORK | capi.RT_FLAG_REFERENCE_ORDER, stream=sptr)
         stream.synchronize()
-        info[f] = ctx.last_counters()
+        info[f] = ctx.last_counters()                       # the reference's traversal: every box it would test
         assert info[f]["hit_pixels"] == int((hit_id >= 0).sum().item())
+        scene.render(f, W, H, scratch, flags=capi.RT_FLAG_COUNT_WORK, stream=sptr)
+        stream.synchronize()
+        own[f] = ctx.last_counters()                        # the traversal the timed kernel runs (ordered, culled)
     ctx.set_option("timing", 0)
 
     # ---- warm-up
     nb = (a.steps + a.batch - 1) // a.batch
     bufs = [torch.empty((a.batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(nb)]
-    for i in range(a.warmup):
-        scene.render(seq[i], W, H, bufs[0][i % a.batch], stream=sptr)
+    for i in range(0, a.warmup, a.batch):
+        fr = seq[i:min(i + a.batch, a.warmup)]
+        scene.render_frames(fr, W, H, bufs[0], stream=sptr)
     if world > 1:
         g = sharding.FrameGather(rank, world)
         g.submit(bufs[0])
@@ -150,10 +153,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        b, k = divmod(i, a.batch)
-        scene.render(seq[a.warmup + i], W, H, bufs[b][k], stream=sptr)
-        if gather is not None and (k == a.batch - 1 or i == a.steps - 1):
+    for b in range(nb):
+        fr = seq[a.warmup + b * a.batch:a.warmup + min((b + 1) * a.batch, a.steps)]
+        scene.render_frames(fr, W, H, bufs[b], stream=sptr)
+        if gather is not None:
             gather.submit(bufs[b])
     if gather is not None:
         gather.finish()
@@ -173,33 +176,53 @@ def main():
     else:
         dt_all, rays_all = dt, float(rays_rank)
 
-    # ---- kernel duration with HIP events on the launch stream (rank 0), one launch at a time
-    roof = None
+    # ---- kernel duration with HIP events on the launch stream (rank 0): the same launches as the
+    # timed region, one at a time
+    roof, single_ms = None, None
     if rank == 0:
         ctx.set_option("timing", 1)
-        ms, alg_bytes, alg_flops = [], [], []
-        for f in seq[a.warmup:]:
-            scene.render(f, W, H, bufs[0][0], stream=sptr)
-            ms.append(ctx.last_kernel_ms())
-            c = info[f]
+
+        def work(c):
             rays = c["primary_rays"] + c["shadow_rays"]
-            alg_bytes.append(c["slab_tests"] * B_SLAB + c["tri_tests"] * B_TRI + c["hit_pixels"] * B_HIT + W * H * B_PIXEL)
-            alg_flops.append(c["slab_tests"] * F_SLAB + c["tri_tests"] * F_TRI + rays * 3 * F_XFORM)
+            return (c["slab_tests"] * B_SLAB + c["tri_tests"] * B_TRI + c["hit_pixels"] * B_HIT + W * H * B_PIXEL,
+                    c["slab_tests"] * F_SLAB + c["tri_tests"] * F_TRI + rays * 3 * F_XFORM)
+        ms, alg_bytes, alg_flops, own_bytes, own_flops = [], [], [], [], []
+        for b in range(nb):
+            fr = seq[a.warmup + b * a.batch:a.warmup + min((b + 1) * a.batch, a.steps)]
+            scene.render_frames(fr, W, H, bufs[0], stream=sptr)
+            ms.append(ctx.last_kernel_ms())
+            alg_bytes.append(sum(work(info[f])[0] for f in fr)); alg_flops.append(sum(work(info[f])[1] for f in fr))
+            own_bytes.append(sum(work(own[f])[0] for f in fr)); own_flops.append(sum(work(own[f])[1] for f in fr))
         kern_ms = float(np.mean(ms))
         gbs = float(np.mean(alg_bytes)) / (kern_ms * 1e-3) / 1e9
         tfl = float(np.mean(alg_flops)) / (kern_ms * 1e-3) / 1e12
         roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "render kernel (variant %d, block %d)" % (ctx.get_option("variant"), ctx.get_option("block")),
+                "kernel": "render_batch (block %d), %d frames per launch" % (ctx.get_option("block"), a.batch),
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(np.mean(alg_bytes)),
+                "basis": "reference-equivalent traversal (every box and triangle test scene.c/bvh.c would run)",
                 "valu": {"achieved": round(tfl, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tfl / VALU_PEAK_TFLOPS, 5)},
-                "note": "scene (77 KB of nodes, 170 KB of triangles) is cache resident: algorithmic bytes are "
-                        "served by L1/L2/LDS, not HBM; see DESIGN.md"}
+                "kernel_counted": {"bytes_per_launch": int(np.mean(own_bytes)),
+                                   "GB/s": round(float(np.mean(own_bytes)) / (kern_ms * 1e-3) / 1e9, 1),
+                                   "TFLOP/s": round(float(np.mean(own_flops)) / (kern_ms * 1e-3) / 1e12, 3),
+                                   "basis": "tests the ordered, distance-culled traversal of the kernel executes"},
+                "note": "the scene (150 KB of nodes, 170 KB of triangles) is cache resident: these bytes are served by "
+                        "L1/L2, not HBM; the kernel is bound by FP32 VALU issue under divergence"}
+        # one frame launched alone (its duration is set by its slowest tiles)
+        one = []
+        for f in sorted(set(seq[a.warmup:]))[:8]:
+            scene.render(f, W, H, bufs[0][0], stream=sptr)
+            one.append(ctx.last_kernel_ms())
+        single_ms = round(float(np.mean(one)), 4)
         tr = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tr):
-            try:
-                roof["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
+            try:                                              # counters of an earlier rocprofv3 --pmc run (scripts/gpu_pmc.sh)
+                pmc = json.load(open(tr))
+                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+                roof["traffic_note"] = "HBM bytes per %s launch of 8 frames from FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, profiles/traffic.json" % pmc.get("kernel")
+                roof["valu"]["issue_utilisation_pmc"] = pmc.get("valu_issue_utilisation")
+                roof["valu"]["lane_utilisation_pmc"] = pmc.get("valu_lane_utilisation")
             except Exception:
                 pass
 
@@ -217,10 +240,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "reference scene assets (drone/treasure/ground OBJ + WebP), animation frames of raytracer.c",
             "config": {"workload": f"{W}x{H} frame, 1 primary ray/pixel + 1 shadow ray/hit pixel, 3 meshes (3625 triangles)",
-                       "frames_per_rank": a.steps, "sharding": "frame f on rank f mod N" if world > 1 else "single GPU",
+                       "frames_per_rank": a.steps, "frames_per_launch": a.batch, "sharding": "frame f on rank f mod N" if world > 1 else "single GPU",
                        "gather": f"RGB8 framebuffers to rank 0 over RCCL, {a.batch} frames per message" if world > 1 else "none"},
             "frames_per_s": round(a.steps * world / dt_all, 2),
             "rays_per_frame": int(rays_rank / a.steps),
+            "single_frame_kernel_ms": single_ms,
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -35,6 +35,7 @@ typedef enum {
 #define RT_MAX_MESHES        8          /* meshes per scene (one BVH each, reference scene.c:72) */
 #define RT_MAX_TREE_DEPTH    30         /* deepest BVH the traversal stack covers */
 #define RT_MAX_MESH_TRIS     (1 << 24)  /* triangles per mesh */
+#define RT_MAX_BATCH         16         /* frames per rt_render_frames call */
 
 /* ---- reference-layout structs ---------------------------------------------------------- */
 typedef struct { float x, y, z; } rt_vec3;                       /* math/vec3.h:6 */
@@ -123,6 +124,18 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
                     int32_t width, int32_t height, uint32_t flags,
                     void* d_rgb, void* d_hit_id, void* d_hit_t, void* d_shadow, void* stream);
 
+/* The reference's frame loop (raytracer.c:47-59: set_mesh_position / set_mesh_rotation, render_scene,
+ * next_frame, repeated) for n_frames consecutive frames in ONE launch.  Frames of an animation are
+ * independent; rendering them together lets the few long-running tiles of every frame overlap with the
+ * bulk of the others, which is what makes the frame rate work-bound.  transforms holds
+ * n_frames * n_transforms entries, frame after frame; camera and light are shared.  Frame f is written
+ * to (uint8_t*)d_rgb + f * frame_stride (frame_stride >= width*height*3, in bytes), same pixel layout
+ * as rt_render_frame, same bytes as n_frames calls of rt_render_frame would give.  Asynchronous on
+ * `stream`; the transforms are consumed before the call returns.  1 <= n_frames <= RT_MAX_BATCH. */
+int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
+                     const rt_transform* transforms, int32_t n_frames, int32_t n_transforms,
+                     int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream);
+
 /* Same, for callers that hold host buffers (what scene->frames[current_frame] is in the
  * reference): renders into context-owned device planes, waits, and copies back. */
 int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
@@ -143,9 +156,13 @@ int rt_last_counters(rt_ctx* ctx, rt_counters* out);
  * must hold 16 bytes per tile of the frames rendered; NULL switches tracing off. */
 int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
 
-/* Tunables, by name: "variant" (kernel variant id, 0 <= id < "n_variants"), "block" (threads per
- * workgroup: 64, 128 or 256), "timing" (record HIP events around each launch, default 1).
- * Read-only: "n_variants", "default_variant".  Unknown names give RT_ERR_INVALID. */
+/* Tunables, by name: "variant" (kernel variant id of rt_render_frame, 0 <= id < "n_variants"), "block"
+ * (threads per workgroup: 64, 128 or 256), "timing" (record HIP events around each launch, default 1),
+ * "coop" (variant 3: 0 off, 1 cooperative tiles where primary or shadow rays can meet a big mesh,
+ * 2 primary rays only), "budget" (variant 4: node visits one lane spends on a pixel before the pixel is
+ * handed to the cooperative pass), "resident_budget" (variants 5..9: bytes of small meshes staged in LDS).
+ * Every setting produces the same image.  Read-only: "n_variants", "default_variant".
+ * Unknown names give RT_ERR_INVALID. */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);
 int rt_get_option(const rt_ctx* ctx, const char* name, int* value);
 

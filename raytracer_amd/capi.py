@@ -20,6 +20,7 @@ RT_ERR_INVALID, RT_ERR_DEVICE, RT_ERR_NO_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_CAPA
 RT_FLAG_COUNT_WORK = 0x1
 RT_FLAG_REFERENCE_ORDER = 0x2
 RT_MAX_MESHES = 8
+RT_MAX_BATCH = 16
 
 
 class Vec3(C.Structure):
@@ -54,7 +55,7 @@ EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_bvh_build", "rt_bvh_flatten_tree",
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
-    "rt_set_trace_buffer",
+    "rt_set_trace_buffer", "rt_render_frames",
 ]
 
 _lib = None
@@ -101,6 +102,8 @@ def lib():
                                       vp, vp, vp, vp, vp]
         L.rt_render_frame_host.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, u32,
                                            vp, vp, vp, vp]
+        L.rt_render_frames.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, i32,
+                                       vp, C.c_size_t, vp]
         L.rt_sync.argtypes = [vp, vp]
         L.rt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.rt_last_counters.argtypes = [vp, C.POINTER(Counters)]
@@ -210,6 +213,20 @@ class Context:
         self._check(lib().rt_render_frame(self._h, C.byref(camera), C.byref(light), arr, len(transforms), int(width),
                                           int(height), int(flags), _dev_ptr(rgb), _dev_ptr(hit_id), _dev_ptr(hit_t),
                                           _dev_ptr(shadow), stream))
+
+    def render_frames(self, camera: Camera, light: Light, transforms: Sequence[Sequence[Transform]], width: int, height: int,
+                      rgb, frame_stride: Optional[int] = None, stream: Optional[int] = None):
+        """rt_render_frames: transforms[f] are the placements of frame f; frame f lands at rgb + f*frame_stride
+        (default: images back to back, i.e. a [n_frames, height, width, 3] uint8 tensor)."""
+        n = len(transforms)
+        m = len(transforms[0]) if n else 0
+        flat = [t for frame in transforms for t in frame]
+        if len(flat) != n * m:
+            raise ValueError("every frame needs the same number of transforms")
+        arr = (Transform * max(len(flat), 1))(*flat)
+        stride = int(frame_stride) if frame_stride is not None else int(width) * int(height) * 3
+        self._check(lib().rt_render_frames(self._h, C.byref(camera), C.byref(light), arr, n, m, int(width), int(height),
+                                           _dev_ptr(rgb), stride, stream))
 
     def render_host(self, camera: Camera, light: Light, transforms: Sequence[Transform], width: int, height: int,
                     debug: bool = True, flags: int = 0):

@@ -16,6 +16,8 @@ using namespace rt;
 
 namespace {
 
+constexpr int kBatchSlots = 4;
+
 struct DeviceMesh {
     std::vector<PairNode> pairs;   // host copy; the device copy lives in the scene's combined array
     std::vector<TriRec> tris;      // host copy, for the LDS-resident blob
@@ -57,6 +59,13 @@ struct rt_ctx {
     int budget = 48;               // two-pass variant: node visits per pixel before it is deferred
     int resident_budget = (int)kResidentBudget;   // bytes of small meshes staged in LDS by the lean kernels
     int coop = 1;                  // cooperative rendering of the big meshes' screen area (variant 3)
+    // rt_render_frames: per-frame constants travel through a ring of staging slots (pinned host
+    // copy -> device copy on the caller's stream); a slot is reused once its event has completed.
+    FrameArgs* h_batch = nullptr;
+    FrameArgs* d_batch = nullptr;
+    hipEvent_t batch_done[kBatchSlots] = {};
+    bool batch_used[kBatchSlots] = {};
+    unsigned batch_seq = 0;
     std::string err;
 };
 
@@ -141,6 +150,50 @@ int commit_scene(rt_ctx* ctx) {
     return RT_OK;
 }
 
+SceneArgs scene_args(const rt_ctx* ctx) {
+    SceneArgs S;
+    S.pairs = ctx->d_all_pairs; S.n_pairs = ctx->n_all_pairs; S.stack_entries = ctx->stack_entries;
+    S.resident = ctx->d_resident; S.resident_bytes = ctx->resident_bytes;
+    return S;
+}
+
+// Per-frame constants: camera basis, light, and each mesh's placement (inverse matrices, camera
+// origin and light direction in mesh space).
+void fill_frame(const rt_ctx* ctx, const rt_camera& camera, const rt_light& light, const rt_transform* transforms, int32_t n_transforms,
+                int32_t width, int32_t height, uint32_t flags, FrameArgs& A) {
+    memset(&A, 0, sizeof(A));
+    fill_camera(camera, light, width, height, A);
+    A.n_mesh = n_transforms;
+    A.flags = flags;
+    for (int32_t m = 0; m < n_transforms; m++) {
+        A.mesh[m] = ctx->meshes[(size_t)m].proto;
+        fill_placement(transforms[m], A, A.mesh[m]);
+    }
+}
+
+// First tile row (8-pixel rows) of the screen area in which a ray of this frame, primary or
+// shadow, can meet a big mesh; -1 when there is no big mesh or the area cannot be bounded.
+int first_heavy_row(const rt_transform* transforms, int32_t n_transforms, const FrameArgs& A) {
+    std::vector<WorldBox> boxes((size_t)n_transforms);
+    double slo[3] = {1e300, 1e300, 1e300}, shi[3] = {-1e300, -1e300, -1e300};
+    for (int32_t m = 0; m < n_transforms; m++) {
+        boxes[(size_t)m] = world_box(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max);
+        if (A.mesh[m].empty) continue;
+        for (int i = 0; i < 3; i++) {
+            slo[i] = boxes[(size_t)m].lo[i] < slo[i] ? boxes[(size_t)m].lo[i] : slo[i];
+            shi[i] = boxes[(size_t)m].hi[i] > shi[i] ? boxes[(size_t)m].hi[i] : shi[i];
+        }
+    }
+    int row = -1;
+    for (int32_t m = 0; m < n_transforms; m++) {
+        if (A.mesh[m].pair_count < kBigMeshPairs) continue;
+        int r[4];
+        if (!coop_rect(boxes[(size_t)m], slo, shi, A, true, r)) return -1;
+        if (r[2] > r[0] && r[3] > r[1] && (row < 0 || r[1] < row)) row = r[1];
+    }
+    return row;
+}
+
 int ensure_planes(rt_ctx* ctx, size_t pixels) {
     if (pixels <= ctx->plane_pixels) return RT_OK;
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
@@ -193,6 +246,10 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (e == hipSuccess) e = hipMemset(ctx->d_queue, 0, sizeof(TileQueue));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_defer, sizeof(DeferQueue));
     if (e == hipSuccess) e = hipMemset(ctx->d_defer, 0, sizeof(DeferQueue));
+    const size_t batch_bytes = (size_t)kBatchSlots * RT_MAX_BATCH * sizeof(FrameArgs);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_batch, batch_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_batch, batch_bytes);
+    for (int i = 0; i < kBatchSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->batch_done[i], hipEventDisableTiming);
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) { ctx->cfg.queue = ctx->d_queue; ctx->cfg.n_cus = cus > 0 ? cus : 256; }
@@ -216,6 +273,13 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     if (ctx->d_defer) (void)hipFree(ctx->d_defer);
     if (ctx->d_defer_items) (void)hipFree(ctx->d_defer_items);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    for (int i = 0; i < kBatchSlots; i++) {
+        if (!ctx->batch_done[i]) continue;
+        if (ctx->batch_used[i]) (void)hipEventSynchronize(ctx->batch_done[i]);
+        (void)hipEventDestroy(ctx->batch_done[i]);
+    }
+    if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
     if (ctx->d_id) (void)hipFree(ctx->d_id);
     if (ctx->d_t) (void)hipFree(ctx->d_t);
@@ -314,19 +378,10 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     int cst = commit_scene(ctx);
     if (cst != RT_OK) return cst;
-    SceneArgs S;
-    S.pairs = ctx->d_all_pairs; S.n_pairs = ctx->n_all_pairs; S.stack_entries = ctx->stack_entries;
-    S.resident = ctx->d_resident; S.resident_bytes = ctx->resident_bytes;
+    const SceneArgs S = scene_args(ctx);
 
     FrameArgs A;
-    memset(&A, 0, sizeof(A));
-    fill_camera(*camera, *light, width, height, A);
-    A.n_mesh = n_transforms;
-    A.flags = flags;
-    for (int32_t m = 0; m < n_transforms; m++) {
-        A.mesh[m] = ctx->meshes[(size_t)m].proto;
-        fill_placement(transforms[m], A, A.mesh[m]);
-    }
+    fill_frame(ctx, *camera, *light, transforms, n_transforms, width, height, flags, A);
     // Work layout: screen rectangles where rays can meet a big mesh are rendered cooperatively and
     // launched first.  Not used when the caller asks for the reference's visiting order or for work
     // counts, when a rectangle cannot be bounded, or when they cover more than a quarter of the frame.
@@ -390,6 +445,45 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
         return hip_fail(ctx, le, "kernel launch");
     }
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
+    return RT_OK;
+}
+
+int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms, int32_t n_frames,
+                     int32_t n_transforms, int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!camera || !light || !d_rgb) return fail(ctx, RT_ERR_INVALID, "camera, light and d_rgb are required");
+    if (n_frames < 1 || n_frames > RT_MAX_BATCH) return fail(ctx, RT_ERR_INVALID, "n_frames must be 1..RT_MAX_BATCH");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    if (frame_stride < (size_t)width * (size_t)height * 3) return fail(ctx, RT_ERR_INVALID, "frame_stride smaller than one image");
+    if (n_transforms != (int32_t)ctx->meshes.size() || (n_transforms > 0 && !transforms))
+        return fail(ctx, RT_ERR_INVALID, "one transform per uploaded mesh and frame is required");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int cst = commit_scene(ctx);
+    if (cst != RT_OK) return cst;
+    const SceneArgs S = scene_args(ctx);
+
+    const int slot = (int)(ctx->batch_seq++ % (unsigned)kBatchSlots);
+    if (ctx->batch_used[slot]) RT_HIP(ctx, hipEventSynchronize(ctx->batch_done[slot]));
+    FrameArgs* h = ctx->h_batch + (size_t)slot * RT_MAX_BATCH;
+    FrameArgs* d = ctx->d_batch + (size_t)slot * RT_MAX_BATCH;
+    int first_row = -1;
+    bool bounded = true;
+    for (int32_t f = 0; f < n_frames; f++) {
+        const rt_transform* tf = transforms ? transforms + (size_t)f * (size_t)n_transforms : nullptr;
+        fill_frame(ctx, *camera, *light, tf, n_transforms, width, height, 0u, h[f]);
+        const int row = first_heavy_row(tf, n_transforms, h[f]);
+        if (row < 0) bounded = false;
+        else if (first_row < 0 || row < first_row) first_row = row;
+    }
+    if (!bounded || first_row < 0) first_row = 0;
+    RT_HIP(ctx, hipMemcpyAsync(d, h, (size_t)n_frames * sizeof(FrameArgs), hipMemcpyHostToDevice, s));
+    if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
+    hipError_t le = launch_batch(d, n_frames, width, height, S, (uint8_t*)d_rgb, frame_stride, first_row, ctx->cfg.block, s);
+    if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
+    if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
+    RT_HIP(ctx, hipEventRecord(ctx->batch_done[slot], s));
+    ctx->batch_used[slot] = true;
     return RT_OK;
 }
 

@@ -8,12 +8,12 @@
 namespace rt {
 
 constexpr int kNumVariants = 10;     // kernel variants selectable through LaunchConfig::variant
-constexpr int kDefaultVariant = 4;
+constexpr int kDefaultVariant = 0;
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 
 struct LaunchConfig {
     int variant = kDefaultVariant;   // kernel variant id (see rt_kernels.hip)
-    int block = 256;                 // threads per workgroup (variant 0)
+    int block = 64;                  // threads per workgroup: 64, 128 or 256
     int n_cus = 256;                 // compute units of the device (grid of the persistent variant)
     TileQueue* queue = nullptr;      // zero-initialised device words owned by the context
     // two-pass variant: list of deferred pixels (y*width+x), its counters, and which counter this frame uses
@@ -32,5 +32,11 @@ bool resident_fits(const SceneArgs& S);
 // width*height*3 bytes and the optional planes width*height elements.  Launches that share a
 // TileQueue must be ordered one after another (same stream, or synchronised by the caller).
 hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, const LaunchConfig& cfg, hipStream_t stream);
+
+// Enqueues n_frames frames of width x height in one launch.  d_frames is a device array of n_frames
+// FrameArgs (same size, flags 0), rgb receives frame f at rgb + f*frame_stride; tile rows are
+// scanned starting at first_row.  block: 64 or 256.
+hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb, size_t frame_stride,
+                        int first_row, int block, hipStream_t stream);
 
 }  // namespace rt

@@ -192,6 +192,73 @@ static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const Outp
 }
 
 // ------------------------------------------------------------------------------------------
+// Batched frames: one launch renders n_frames frames of the same size into consecutive images.
+//
+// A frame has a few tiles whose rays run several hundred microseconds (they cross a big mesh)
+// while the bulk of the frame is done in far less; rendered alone, the frame lasts as long as
+// those tiles.  Frames are independent, so a batch puts the long tiles of ALL its frames at the
+// front of one grid (rows are scanned from first_row, the top of the big meshes' screen area,
+// and wrap around) and the cheap tiles of all frames fill the machine behind them.  Wave w
+// renders tile w / n_frames of frame w % n_frames.  The per-frame constants come from an array
+// in device memory; the frame index is uniform per wave, so they are read with scalar loads.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int DEPTH, uint32_t LB>
+__global__ void __launch_bounds__(BLOCK) render_batch(const FrameArgs* __restrict__ frames, const int n_frames, const SceneArgs S,
+                                                      uint8_t* __restrict__ rgb_base, const unsigned long long frame_stride,
+                                                      const int first_row) {
+    __shared__ uint32_t lds_stack[DEPTH * BLOCK];
+    LdsStack<BLOCK> stack;
+    stack.base = &lds_stack[threadIdx.x];
+    stack.sp = 0;
+    GlobalNodes nodes; nodes.all = S.pairs;
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)));
+    const int slot = wave / n_frames;
+    const int f = wave - slot * n_frames;
+    const FrameArgs& A = frames[f];
+    const int tiles_x = (A.width + 7) >> 3, tiles_y = (A.height + 7) >> 3;
+    if (slot >= tiles_x * tiles_y) return;
+    int row = slot / tiles_x;
+    const int col = slot - row * tiles_x;
+    row += first_row;
+    if (row >= tiles_y) row -= tiles_y;
+    const int lane = threadIdx.x & 63;
+    const int px = col * 8 + (lane & 7), py = row * 8 + (lane >> 3);
+    if (px < A.width && py < A.height) {
+        Work work; work.slabs = 0; work.tris = 0;
+        const PixelOut r = shade_pixel<false, false, false>(A, nodes, SoloT<LB>(), px, py, stack, work);
+        uint8_t* rgb = rgb_base + (size_t)f * frame_stride + ((size_t)py * (size_t)A.width + (size_t)px) * 3;
+        rgb[0] = r.r; rgb[1] = r.g; rgb[2] = r.b;
+    }
+}
+
+template <int BLOCK, int DEPTH>
+static hipError_t launch_batch_t(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb,
+                                 size_t frame_stride, int first_row, hipStream_t stream) {
+    const long long tiles = (long long)((width + 7) / 8) * ((height + 7) / 8);
+    const long long waves = tiles * n_frames;
+    const int waves_per_block = BLOCK / 64;
+    const long long blocks = (waves + waves_per_block - 1) / waves_per_block;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((render_batch<BLOCK, DEPTH, kLeafBatch>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, d_frames, n_frames, S, rgb,
+                       (unsigned long long)frame_stride, first_row);
+    return hipGetLastError();
+}
+
+hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb, size_t frame_stride,
+                        int first_row, int block, hipStream_t stream) {
+    if (n_frames <= 0 || width <= 0 || height <= 0 || !d_frames || !rgb) return hipErrorInvalidValue;
+    const int tiles_y = (height + 7) / 8;
+    if (first_row < 0 || first_row >= tiles_y) first_row = 0;
+    if (S.stack_entries <= 16) {
+        if (block == 64) return launch_batch_t<64, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, stream);
+        return launch_batch_t<256, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, stream);
+    }
+    if (block == 64) return launch_batch_t<64, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, stream);
+    return launch_batch_t<256, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, stream);
+}
+
+// ------------------------------------------------------------------------------------------
 // Variant 3: tiles, with cooperative groups where rays are long.
 //
 // A ray through a big mesh visits hundreds of nodes (the reference's traversal has no distance

@@ -47,6 +47,11 @@ class DemoScene:
         self.ctx.render(self.camera, self.light, self.transforms(frame), width, height, rgb, hit_id, hit_t, shadow,
                         flags=flags, stream=stream)
 
+    def render_frames(self, frames, width: int, height: int, rgb, stream=None):
+        """One launch for several animation frames; rgb is a [len(frames), height, width, 3] uint8 device tensor."""
+        self.ctx.render_frames(self.camera, self.light, [self.transforms(f) for f in frames], width, height, rgb,
+                               stream=stream)
+
     def close(self):
         H = host_api.lib()
         self.ctx.close()

@@ -19,6 +19,7 @@ def main():
     p.add_argument("--block", type=int, default=0)
     p.add_argument("--frames", default="0,45,90")
     p.add_argument("--repeat", type=int, default=2)
+    p.add_argument("--batch", type=int, default=0, help="> 0: rt_render_frames with this many consecutive frames per launch")
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     a = p.parse_args()
@@ -30,10 +31,13 @@ def main():
     if a.block:
         scene.ctx.set_option("block", a.block)
     scene.ctx.set_option("timing", 0)
-    buf = torch.empty((a.height, a.width, 3), dtype=torch.uint8, device=dev)
+    buf = torch.empty((max(a.batch, 1), a.height, a.width, 3), dtype=torch.uint8, device=dev)
     for _ in range(a.repeat):
         for f in a.frames.split(","):
-            scene.render(int(f), a.width, a.height, buf)
+            if a.batch > 0:
+                scene.render_frames([(int(f) + i) % demo.N_FRAMES for i in range(a.batch)], a.width, a.height, buf)
+            else:
+                scene.render(int(f), a.width, a.height, buf[0])
     scene.ctx.sync()
     torch.cuda.synchronize()
     scene.close()

@@ -142,7 +142,63 @@ def test_all_kernel_variants_agree(capi, ctx, po, golden_frames):
                 assert_frame_equal(got, g["f45_rgb"], g["f45_hit_id"], g["f45_hit_t"], g["f45_shadow"])
     finally:
         ctx.set_option("variant", ctx.get_option("default_variant"))
-        ctx.set_option("block", 256)
+        ctx.set_option("block", 64)
+
+
+@pytest.mark.parametrize("block", [64, 256])
+def test_batched_frames_equal_single_frames(capi, ctx, po, golden_hashes, block):
+    """rt_render_frames: every frame of a batch carries the bytes the single-frame entry point produces."""
+    import torch
+    cam, light = cam_light(capi, po)
+    w, h = 720, 540
+    dev = torch.device("cuda:0")
+    frames = [0, 45, 95, 17, 0]
+    tfs = [to_capi_tfs(capi, po.animation_transforms(f)) for f in frames]
+    stream = torch.cuda.Stream(device=dev)
+    try:
+        ctx.set_option("block", block)
+        # images back to back, and with a padded stride
+        out = torch.zeros((len(frames), h, w, 3), dtype=torch.uint8, device=dev)
+        ctx.render_frames(cam, light, tfs, w, h, out, stream=stream.cuda_stream)
+        stride = w * h * 3 + 4096
+        padded = torch.full((len(frames) * stride,), 7, dtype=torch.uint8, device=dev)
+        ctx.render_frames(cam, light, tfs, w, h, padded, frame_stride=stride, stream=stream.cuda_stream)
+        stream.synchronize()
+        for i, f in enumerate(frames):
+            img = out[i].cpu().numpy()
+            if f in (0, 45, 95):
+                assert sha(img) == golden_hashes["frames"][f"{w}x{h}_f{f}"]["rgb"]
+            else:
+                single = ctx.render_host(cam, light, tfs[i], w, h, debug=False)[0]
+                assert np.array_equal(img, single)
+            chunk = padded[i * stride:(i + 1) * stride].cpu().numpy()
+            assert np.array_equal(chunk[:w * h * 3].reshape(h, w, 3), img)
+            assert (chunk[w * h * 3:] == 7).all()                       # padding untouched
+        # ragged size, one frame, more frames than slots in flight
+        small = torch.zeros((3, 5, 7, 3), dtype=torch.uint8, device=dev)
+        for _ in range(6):
+            ctx.render_frames(cam, light, tfs[:3], 7, 5, small, stream=stream.cuda_stream)
+        stream.synchronize()
+        for i in range(3):
+            assert np.array_equal(small[i].cpu().numpy(), ctx.render_host(cam, light, tfs[i], 7, 5, debug=False)[0])
+    finally:
+        ctx.set_option("block", 64)
+
+
+def test_batched_frames_argument_errors(capi, ctx, po):
+    import torch
+    cam, light = cam_light(capi, po)
+    tfs = to_capi_tfs(capi, po.animation_transforms(0))
+    buf = torch.zeros((2, 8, 8, 3), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(capi.RtError) as e:
+        ctx.render_frames(cam, light, [tfs] * (capi.RT_MAX_BATCH + 1), 8, 8, buf)
+    assert e.value.status == capi.RT_ERR_INVALID
+    with pytest.raises(capi.RtError):
+        ctx.render_frames(cam, light, [tfs[:2], tfs[:2]], 8, 8, buf)            # one transform per mesh
+    with pytest.raises(capi.RtError):
+        ctx.render_frames(cam, light, [tfs, tfs], 8, 8, buf, frame_stride=100)   # stride below one image
+    with pytest.raises(capi.RtError):
+        ctx.render_frames(cam, light, [tfs], 0, 8, buf)
 
 
 def test_device_buffers_async_and_deterministic(capi, ctx, po, golden_hashes):
