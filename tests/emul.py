@@ -1,0 +1,119 @@
+"""ctypes wrapper of tests/host_emul/libemul.so: the product's packer (rt_pack.h) and pixel
+pipeline (rt_pixel.h) compiled for the host, so that they can be checked against the oracle on a
+machine without a GPU.  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(HERE, "host_emul", "libemul.so")
+
+_lib = None
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Transform(C.Structure):
+    _fields_ = [("position", Vec3), ("rotation", Vec3)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", Vec3), ("look_at", Vec3), ("up", Vec3), ("fov", C.c_float)]
+
+
+class Light(C.Structure):
+    _fields_ = [("direction", Vec3), ("color", Vec3)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("primary_rays", "shadow_rays", "slab_tests", "tri_tests", "hit_pixels", "shadowed_pixels")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(PATH):
+            raise RuntimeError(f"{PATH} missing: run `make` at the repo root")
+        L = C.CDLL(PATH)
+        vp, i32 = C.c_void_p, C.c_int32
+        L.emul_scene_create.restype = vp
+        L.emul_scene_destroy.argtypes = [vp]
+        L.emul_last_error.argtypes = [vp]
+        L.emul_last_error.restype = C.c_char_p
+        L.emul_stack_high.argtypes = [vp]
+        L.emul_mesh_add.argtypes = [vp, vp, i32, vp, i32, vp, i32, i32]
+        L.emul_mesh_info.argtypes = [vp, C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_uint32)]
+        L.emul_mesh_prios.argtypes = [vp, C.c_int, vp]
+        L.emul_placement.argtypes = [C.POINTER(Transform), C.POINTER(Camera), C.POINTER(Light), vp, vp, vp, vp,
+                                     C.POINTER(C.c_uint32)]
+        L.emul_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32,
+                                  vp, vp, vp, vp, C.POINTER(Counters), i32, vp, vp]
+        _lib = L
+    return _lib
+
+
+def conv(obj, cls):
+    """Copies an oracle ctypes struct (same layout) into this module's struct type."""
+    out = cls()
+    C.memmove(C.byref(out), C.byref(obj), C.sizeof(cls))
+    return out
+
+
+class Scene:
+    def __init__(self):
+        self.h = lib().emul_scene_create()
+        self.n = 0
+        self._keep = []
+
+    def add(self, tris, nodes, rgba) -> int:
+        tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 24)
+        nodes = np.ascontiguousarray(nodes)
+        rgba = np.ascontiguousarray(rgba, np.uint8)
+        self._keep.append((tris, nodes, rgba))
+        st = lib().emul_mesh_add(self.h, tris.ctypes.data, tris.shape[0], nodes.ctypes.data, nodes.shape[0],
+                                 rgba.ctypes.data, rgba.shape[1], rgba.shape[0])
+        if st == 0:
+            self.n += 1
+        return st
+
+    def error(self) -> str:
+        return lib().emul_last_error(self.h).decode()
+
+    def info(self, mesh):
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_uint32(0)
+        assert lib().emul_mesh_info(self.h, mesh, C.byref(a), C.byref(b), C.byref(c)) == 0
+        return {"pairs": a.value, "depth": b.value, "root_ref": c.value}
+
+    def prios(self, mesh, n):
+        out = np.zeros(n, np.uint32)
+        assert lib().emul_mesh_prios(self.h, mesh, out.ctypes.data) == 0
+        return out
+
+    def render(self, cam, light, tfs, w, h, full=False, per_pixel=False):
+        arr = (Transform * max(len(tfs), 1))(*[conv(t, Transform) for t in tfs])
+        rgb = np.zeros((h, w, 3), np.uint8)
+        hid = np.zeros((h, w), np.int32)
+        ht = np.zeros((h, w), np.float32)
+        sh = np.zeros((h, w), np.uint8)
+        cnt = Counters()
+        ps = np.zeros((h, w), np.uint32) if per_pixel else None
+        pt = np.zeros((h, w), np.uint32) if per_pixel else None
+        cam2, light2 = conv(cam, Camera), conv(light, Light)
+        st = lib().emul_render(self.h, C.byref(cam2), C.byref(light2), arr, len(tfs), w, h, rgb.ctypes.data,
+                               hid.ctypes.data, ht.ctypes.data, sh.ctypes.data, C.byref(cnt), 1 if full else 0,
+                               ps.ctypes.data if per_pixel else None, pt.ctypes.data if per_pixel else None)
+        assert st == 0, self.error()
+        return {"rgb": rgb, "hit_id": hid, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(), "px_slabs": ps,
+                "px_tris": pt, "stack_high": lib().emul_stack_high(self.h)}
+
+    def close(self):
+        if self.h:
+            lib().emul_scene_destroy(self.h)
+            self.h = None

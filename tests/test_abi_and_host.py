@@ -1,0 +1,205 @@
+"""CPU-side checks of the product libraries: the C-ABI library loads and exports every symbol its
+header declares, the host-only entry points (BVH build, tree flattening, mesh loading) reproduce the
+reference's results, and rendering entry points fail loudly -- never fall back -- without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO, bits
+
+NAMES = ("drone", "treasure", "ground")
+HEADER = os.path.join(REPO, "include", "rt_mi355.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", text)))
+
+
+def gpu_present():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from raytracer_amd import capi as m
+    m.lib()
+    return m
+
+
+@pytest.fixture(scope="module")
+def host():
+    from raytracer_amd import host_api as m
+    m.lib()
+    return m
+
+
+def test_library_exports_every_declared_symbol(capi):
+    names = declared_functions()
+    assert len(names) >= 19 and "rt_render_frame" in names and "rt_render_frames" in names
+    L = capi.lib()
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/rt_mi355.h but not exported"
+    assert sorted(capi.EXPORTS) == names                     # the Python binding covers the whole header
+    # and the dynamic symbol table holds them as C symbols (no C++ mangling)
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (rt_[a-z_0-9]+)$", out, flags=re.M))
+    assert set(names) <= exported
+
+
+def test_header_compiles_as_c():
+    src = '#include "rt_mi355.h"\nint main(void){ rt_counters c; rt_flat_node n; (void)c; (void)n; return sizeof(rt_triangle) == 96 ? 0 : 1; }\n'
+    exe = "/tmp/rt_header_check"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(REPO, "include"), "-x", "c", "-", "-o", exe],
+                   input=src, text=True, check=True)
+    assert subprocess.run([exe]).returncode == 0
+
+
+def test_host_library_exports_the_reference_api(host):
+    """Names of scene.h:29-36, geometry/mesh.h:22-26, accel/bvh.h:23-28, render/camera.h:15, render/light.h:12."""
+    for n in ("create_scene", "add_mesh_to_scene", "set_scene_camera", "set_scene_light", "next_frame", "render_scene",
+              "save_scene", "destroy_scene", "create_mesh", "set_mesh_position", "set_mesh_rotation", "destroy_mesh",
+              "sample_mesh_texture", "create_bvh_node", "create_bvh", "destroy_bvh_node", "destroy_bvh", "create_camera",
+              "create_directional_light"):
+        assert hasattr(host.lib(), n), n
+
+
+def test_status_strings(capi):
+    assert capi.status_string(0) == "ok"
+    for st in (capi.RT_ERR_INVALID, capi.RT_ERR_DEVICE, capi.RT_ERR_NO_DEVICE, capi.RT_ERR_UNSUPPORTED, capi.RT_ERR_CAPACITY):
+        assert capi.status_string(st) not in ("ok", "unknown status")
+    assert capi.status_string(-99) == "unknown status"
+
+
+def test_no_gpu_means_an_error_not_a_cpu_render(capi, host):
+    if gpu_present():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.RtError) as e:
+        capi.Context(0)
+    assert e.value.status == capi.RT_ERR_NO_DEVICE
+    # null handles are rejected, nothing crashes
+    L = capi.lib()
+    assert L.rt_ctx_destroy(None) == capi.RT_ERR_INVALID
+    assert L.rt_mesh_count(None) == capi.RT_ERR_INVALID
+    assert L.rt_render_frame(None, None, None, None, 0, 8, 8, 0, None, None, None, None, None) == capi.RT_ERR_INVALID
+    assert L.rt_render_frames(None, None, None, None, 1, 0, 8, 8, None, 192, None) == capi.RT_ERR_INVALID
+    # the reference API: render_scene reports the failure and leaves the frame untouched
+    H = host.lib()
+    scene = H.create_scene(64, 48, 1000, 4, 1.0)
+    H.set_scene_camera(C.byref(scene), host.Vec3(-3, 3, -3), host.Vec3(0, 0, 0), host.Vec3(0, 1, 0), 60.0)
+    H.set_scene_light(C.byref(scene), host.Vec3(1, 1, -1), host.Vec3(1.4, 1.4, 1.4))
+    before = host.frame_array(scene, 0)
+    H.render_scene(C.byref(scene))
+    assert H.rt_host_last_status(C.byref(scene)) == capi.RT_ERR_NO_DEVICE
+    assert np.array_equal(host.frame_array(scene, 0), before)
+    H.destroy_scene(C.byref(scene))
+
+
+# ------------------------------------------------------------------------------ host-only entry points
+
+@pytest.mark.parametrize("name", NAMES)
+def test_rt_bvh_build_equals_reference(capi, po, golden_bvh, name):
+    soup = po.load_obj(os.path.join(po.ASSETS, name + ".obj"))
+    post, nodes = capi.build_bvh(soup)
+    assert np.array_equal(post.view(np.uint32), soup[golden_bvh[name + "_perm"]].view(np.uint32))
+    want = golden_bvh[name + "_nodes"]
+    assert nodes.shape == want.shape
+    for f in ("left", "right", "start", "count"):
+        assert np.array_equal(nodes[f], want[f])
+    assert np.array_equal(bits(nodes["bmin"]), bits(want["bmin"])) and np.array_equal(bits(nodes["bmax"]), bits(want["bmax"]))
+
+
+def test_rt_bvh_build_argument_errors(capi):
+    L = capi.lib()
+    used = C.c_int32(0)
+    tris = np.zeros((10, 24), np.float32)
+    tris[:, 0] = np.arange(10)
+    nodes = np.zeros(2, capi.NODE_DTYPE)
+    assert L.rt_bvh_build(tris.ctypes.data, 10, nodes.ctypes.data, 2, C.byref(used)) == capi.RT_ERR_CAPACITY
+    assert L.rt_bvh_build(None, 10, nodes.ctypes.data, 2, C.byref(used)) == capi.RT_ERR_INVALID
+    assert L.rt_bvh_build(tris.ctypes.data, -1, nodes.ctypes.data, 2, C.byref(used)) == capi.RT_ERR_INVALID
+    assert L.rt_bvh_build(tris.ctypes.data, 10, nodes.ctypes.data, 0, C.byref(used)) == capi.RT_ERR_INVALID
+    # no triangles: one empty node, as create_bvh_node(tris, 0, 0) gives
+    assert L.rt_bvh_build(None, 0, nodes.ctypes.data, 2, C.byref(used)) == 0 and used.value == 1
+    assert nodes["count"][0] == 0 and nodes["left"][0] == -1
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_create_mesh_and_flatten_tree_equal_reference(capi, host, po, golden_bvh, golden_hashes, name):
+    """create_mesh (mesh.c:6-119) through the host library: OBJ parse, BVH build in place, texture decode;
+    then rt_bvh_flatten_tree on the pointer tree it leaves in Mesh.bvh.root."""
+    import hashlib
+    H = host.lib()
+    m = H.create_mesh(os.path.join(host.ASSETS, name + ".obj").encode(), os.path.join(host.ASSETS, name + ".webp").encode())
+    try:
+        assert int(m.triangle_count) == golden_hashes["meshes"][name]["triangles"]
+        tris = host.mesh_triangles(m)
+        assert hashlib.sha256(tris.tobytes()).hexdigest() == golden_hashes["meshes"][name]["triangles_post_sha256"]
+        tex = host.mesh_texture(m)
+        assert hashlib.sha256(tex.tobytes()).hexdigest() == golden_hashes["textures"][name]["sha256"]
+        want = golden_bvh[name + "_nodes"]
+        flat = np.zeros(want.shape[0] + 4, capi.NODE_DTYPE)
+        used = C.c_int32(0)
+        st = capi.lib().rt_bvh_flatten_tree(C.cast(m.bvh.root, C.c_void_p), flat.ctypes.data, flat.shape[0], C.byref(used))
+        assert st == 0 and used.value == want.shape[0]
+        flat = flat[:used.value]
+        for f in ("left", "right", "start", "count"):
+            assert np.array_equal(flat[f], want[f])
+        assert np.array_equal(bits(flat["bmin"]), bits(want["bmin"])) and np.array_equal(bits(flat["bmax"]), bits(want["bmax"]))
+        # too small an output array is reported, not overrun
+        small = np.zeros(3, capi.NODE_DTYPE)
+        assert capi.lib().rt_bvh_flatten_tree(C.cast(m.bvh.root, C.c_void_p), small.ctypes.data, 3, C.byref(used)) == capi.RT_ERR_CAPACITY
+        # sample_mesh_texture (mesh.c:136-150) against the oracle's restatement
+        om = po.HostMesh(tris, want, tex).as_struct(po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0)))
+        rng = np.random.default_rng(4)
+        for u, v in np.concatenate([rng.uniform(-1.5, 2.5, size=(200, 2)), [[0, 0], [1, 1], [0.5, 1.0], [1.0, 0.0]]]):
+            rgb = (C.c_float * 3)()
+            po.lib().orc_sample_texture(C.byref(om), float(u), float(v), rgb)
+            got = H.sample_mesh_texture(C.byref(m), float(u), float(v))
+            assert bits(np.array([got.x, got.y, got.z])).tolist() == bits(np.array(list(rgb))).tolist()
+    finally:
+        H.destroy_mesh(C.byref(m))
+    assert not m.triangles and not m.texture_data and not m.bvh.root      # pointers cleared: a second destroy is harmless
+    H.destroy_mesh(C.byref(m))
+
+
+def test_create_mesh_missing_files(host):
+    H = host.lib()
+    m = H.create_mesh(b"/nonexistent/a.obj", b"/nonexistent/a.webp")
+    assert int(m.triangle_count) == 0 and not m.texture_data
+    H.destroy_mesh(C.byref(m))
+
+
+def test_scene_bookkeeping_matches_reference(host):
+    """create_scene scales and allocates (scene.c:8-29); next_frame stops at the last frame (scene.c:48-50)."""
+    H = host.lib()
+    s = H.create_scene(800, 600, 4000, 24, 0.9)
+    assert (s.width, s.height, s.frame_count, s.current_frame) == (720, 540, 96, 0)
+    assert s.duration_ms == 4000 and s.fps == 24 and abs(s.scale_factor - 0.9) < 1e-7
+    for _ in range(200):
+        H.next_frame(C.byref(s))
+    assert s.current_frame == 95
+    cam = H.create_camera(host.Vec3(1, 2, 3), host.Vec3(0, 0, 0), host.Vec3(0, 1, 0), 45.0)
+    assert (cam.position.x, cam.position.y, cam.position.z, cam.fov) == (1, 2, 3, 45.0)
+    lit = H.create_directional_light(host.Vec3(1, 1, -1), host.Vec3(1.4, 1.4, 1.4))
+    n = np.float32(1) / np.sqrt(np.float32(3))
+    assert abs(lit.direction.x - n) < 1e-6 and lit.direction.z < 0
+    H.destroy_scene(C.byref(s))
+
+
+def test_demo_animation_equals_reference_driver(host, po):
+    """Per-frame placements of raytracer.c:40-53."""
+    H = host.lib()
+    for f in (0, 1, 17, 45, 95):
+        d, t = host.Transform(), host.Transform()
+        H.rt_host_demo_animation(f, C.byref(d), C.byref(t))
+        want = po.animation_transforms(f)
+        for got, w in ((d, want[0]), (t, want[1])):
+            g = np.array([got.position.x, got.position.y, got.position.z, got.rotation.x, got.rotation.y, got.rotation.z], np.float32)
+            assert np.array_equal(bits(g), bits(np.array(w.position.tup() + w.rotation.tup(), np.float32)))

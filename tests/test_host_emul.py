@@ -1,0 +1,340 @@
+"""The product's host logic (scene packer, per-frame constants) and its pixel pipeline, compiled for
+the host (tests/host_emul), against the CPU oracle.  Covers what the GPU tests cover, on CPU, plus
+the packer's edge cases: single-leaf and empty meshes, leaves larger than the reference's 4
+triangles, ties, malformed trees.  CPU only."""
+import numpy as np
+import pytest
+
+import emul
+from conftest import bits
+
+
+def node_array(po, rows):
+    a = np.zeros(len(rows), dtype=po.NODE_DTYPE)
+    for i, (lo, hi, left, right, start, count) in enumerate(rows):
+        a[i] = (lo, hi, left, right, start, count)
+    return a
+
+
+def tri_rows(v, uv=None, n=None):
+    """[k,3,3] vertex positions -> [k,24] reference triangles (v0 v1 v2 t0 t1 t2 n0 n1 n2)."""
+    v = np.asarray(v, np.float32)
+    k = v.shape[0]
+    out = np.zeros((k, 24), np.float32)
+    out[:, 0:9] = v.reshape(k, 9)
+    out[:, 9:15] = (0.1, 0.1, 0.9, 0.1, 0.5, 0.9) if uv is None else uv
+    nn = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    nn /= np.maximum(np.linalg.norm(nn, axis=1, keepdims=True), 1e-20)
+    out[:, 15:24] = np.tile(nn, 3) if n is None else n
+    return out
+
+
+def bounds(tris):
+    p = tris[:, 0:9].reshape(-1, 3)
+    return p.min(axis=0), p.max(axis=0)
+
+
+def checker(n=8):
+    t = np.zeros((n, n, 4), np.uint8)
+    t[..., 3] = 255
+    for y in range(n):
+        for x in range(n):
+            t[y, x, :3] = (40 + 25 * x, 30 + 20 * y, 200 - 10 * (x + y))
+    return t
+
+
+def compare(po, em_scene, meshes, tfs, cam, light, w, h, full=False):
+    want = po.render_frame(meshes, tfs, cam, light, w, h)
+    got = em_scene.render(cam, light, tfs, w, h, full=full)
+    assert np.array_equal(got["hit_id"], want.hit_id), f"{(got['hit_id'] != want.hit_id).sum()} ids differ"
+    assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t))
+    assert np.array_equal(got["shadow"], want.shadow)
+    assert np.array_equal(got["rgb"], want.rgb)
+    return got, want
+
+
+@pytest.fixture(scope="module")
+def em_default(meshes):
+    s = emul.Scene()
+    for m in meshes:
+        assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+    yield s
+    s.close()
+
+
+# ------------------------------------------------------------------------------ the reference scene
+
+@pytest.mark.parametrize("frame", [0, 45, 95])
+def test_pipeline_equals_oracle_on_golden_frames(po, meshes, em_default, golden_frames, frame):
+    got, want = compare(po, em_default, meshes, po.animation_transforms(frame), po.default_camera(), po.default_light(), 240, 135)
+    assert np.array_equal(got["rgb"], golden_frames[f"f{frame}_rgb"])
+    assert np.array_equal(got["hit_id"], golden_frames[f"f{frame}_hit_id"])
+
+
+def test_reference_order_mode_does_the_reference_work_exactly(po, meshes, em_default):
+    tfs = po.animation_transforms(45)
+    got, want = compare(po, em_default, meshes, tfs, po.default_camera(), po.default_light(), 200, 112, full=True)
+    assert got["counters"] == want.counters
+    # culled mode: same image, never more work, per pixel
+    fast = em_default.render(po.default_camera(), po.default_light(), tfs, 200, 112, full=False, per_pixel=True)
+    slow = em_default.render(po.default_camera(), po.default_light(), tfs, 200, 112, full=True, per_pixel=True)
+    assert np.array_equal(fast["rgb"], slow["rgb"]) and np.array_equal(fast["hit_id"], slow["hit_id"])
+    assert (fast["px_slabs"] <= slow["px_slabs"]).all() and (fast["px_tris"] <= slow["px_tris"]).all()
+    assert fast["counters"]["slab_tests"] < slow["counters"]["slab_tests"]
+
+
+def test_stack_use_stays_within_tree_depth(po, meshes, em_default):
+    deepest = max(em_default.info(i)["depth"] for i in range(3))
+    for full in (False, True):
+        r = em_default.render(po.default_camera(), po.default_light(), po.animation_transforms(10), 160, 90, full=full)
+        assert 0 < r["stack_high"] <= deepest + 2
+
+
+@pytest.mark.parametrize("size", [(1, 1), (3, 2), (17, 9), (65, 33)])
+def test_ragged_sizes(po, meshes, em_default, size):
+    compare(po, em_default, meshes, po.animation_transforms(77), po.default_camera(), po.default_light(), *size)
+
+
+def test_random_placements_cameras_lights(po, meshes, em_default):
+    rng = np.random.default_rng(5)
+    for _ in range(8):
+        tfs = [po.Transform(po.vec3(*rng.uniform(-1.5, 1.5, 3)), po.vec3(*rng.uniform(-3.2, 3.2, 3))) for _ in range(2)]
+        tfs.append(po.Transform(po.vec3(0, 0, 0), po.vec3(*rng.uniform(-0.05, 0.05, 3))))
+        eye = rng.uniform(-4, 4, 3)
+        eye[1] = abs(eye[1]) + 1.0
+        cam = po.Camera(po.vec3(*eye), po.vec3(0, 0.3, 0), po.vec3(0, 1, 0), float(rng.uniform(30, 90)))
+        light = po.lib().orc_make_light(po.vec3(*rng.uniform(-1, 1, 3)), po.vec3(1.1, 0.9, 1.3))
+        compare(po, em_default, meshes, tfs, cam, light, 96, 54)
+
+
+def test_camera_inside_a_mesh_and_axis_aligned_rays(po, meshes, em_default):
+    """Camera at the treasure's centre looking along an axis: rays start inside boxes, several direction
+    components are exactly zero (1/0 = inf in the slab test)."""
+    tfs = [po.Transform(po.vec3(0, 5, 0), po.vec3(0, 0, 0)), po.Transform(po.vec3(0, 0.5, 0), po.vec3(0, 0, 0)),
+           po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))]
+    cam = po.Camera(po.vec3(0, 0.5, 0), po.vec3(0, 0.5, 1), po.vec3(0, 1, 0), 90.0)
+    compare(po, em_default, meshes, tfs, cam, po.lib().orc_make_light(po.vec3(0, 1, 0), po.vec3(1, 1, 1)), 65, 65)
+    cam = po.Camera(po.vec3(0, 4, 0), po.vec3(0, 0, 0), po.vec3(0, 0, 1), 40.0)           # straight down
+    compare(po, em_default, meshes, tfs, cam, po.lib().orc_make_light(po.vec3(0, 1, 0), po.vec3(1, 1, 1)), 33, 33)
+
+
+def test_per_frame_constants_equal_the_oracles(po):
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    cam, light = po.default_camera(), po.default_light()
+    for k in range(64):
+        pos = rng.uniform(-3, 3, 3) if k >= 8 else np.zeros(3)
+        rot = rng.uniform(-4, 4, 3) if k >= 4 else np.zeros(3)
+        tf = po.Transform(po.vec3(*pos), po.vec3(*rot))
+        inv, nrm = po.mesh_matrices(tf)
+        inv16, nrm9 = np.zeros(16, np.float32), np.zeros(9, np.float32)
+        cam_o, lit_d, mode = np.zeros(3, np.float32), np.zeros(3, np.float32), C.c_uint32(9)
+        tf2, cam2, light2 = emul.conv(tf, emul.Transform), emul.conv(cam, emul.Camera), emul.conv(light, emul.Light)
+        emul.lib().emul_placement(C.byref(tf2), C.byref(cam2), C.byref(light2), inv16.ctypes.data, nrm9.ctypes.data,
+                                  cam_o.ctypes.data, lit_d.ctypes.data, C.byref(mode))
+        assert np.array_equal(bits(inv16.reshape(4, 4)), bits(inv))
+        assert np.array_equal(bits(nrm9.reshape(3, 3)), bits(nrm[:3, :3]))
+        # camera origin in mesh space = transform_ray's origin (ray.c:5-16)
+        r = po.lib().orc_transform_ray(po.Ray(cam.position, po.vec3(0, 0, 1)), tf)
+        assert np.array_equal(bits(cam_o), bits(np.array(r.origin.tup(), np.float32)))
+        assert mode.value in (0, 1, 2)
+
+
+# ------------------------------------------------------------------------------ packer edge cases
+
+def scene_of(po, parts):
+    """parts: list of (tris[k,24], nodes, rgba).  Returns (emul scene, oracle meshes)."""
+    s = emul.Scene()
+    ms = []
+    for tris, nodes, rgba in parts:
+        assert s.add(tris, nodes, rgba) == 0, s.error()
+        ms.append(po.HostMesh(np.ascontiguousarray(tris, np.float32), nodes, rgba))
+    return s, ms
+
+
+def front_camera(po):
+    return po.Camera(po.vec3(0, 0, -4), po.vec3(0, 0, 0), po.vec3(0, 1, 0), 50.0)
+
+
+def identity(po):
+    return po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))
+
+
+def test_mesh_that_is_a_single_leaf(po, meshes):
+    tris = tri_rows([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]], [[-1, -1, 1], [1, -1, 1], [0, 1, 1.5]], [[0.2, 0, -1], [0.9, 0, -1], [0.5, 0.7, -1]]])
+    post, nodes = po.build_bvh(tris)
+    assert nodes.shape[0] == 1
+    s, ms = scene_of(po, [(post, nodes, checker()), (meshes[2].tris, meshes[2].nodes, meshes[2].rgba)])
+    assert s.info(0)["pairs"] == 0 and s.info(0)["root_ref"] & 0x80000000
+    tfs = [po.Transform(po.vec3(0, 1, 0), po.vec3(0.3, 0.2, 0.1)), identity(po)]
+    got, want = compare(po, s, ms, tfs, po.default_camera(), po.default_light(), 120, 68)
+    assert (want.hit_id >> 24 == 0).any() and (want.shadow == 1).any()
+    s.close()
+
+
+def test_empty_mesh_is_accepted_and_never_hit(po, meshes):
+    empty_tris = np.zeros((0, 24), np.float32)
+    post, nodes = po.build_bvh(empty_tris)               # one node, count 0, inverted (empty) box like create_empty_aabb
+    assert nodes.shape[0] == 1 and nodes["count"][0] == 0
+    s, ms = scene_of(po, [(post, nodes, checker()), (meshes[0].tris, meshes[0].nodes, meshes[0].rgba)])
+    tfs = [identity(po), po.animation_transforms(3)[0]]
+    got, want = compare(po, s, ms, tfs, po.default_camera(), po.default_light(), 100, 60)
+    assert not (want.hit_id >> 24 == 0)[want.hit_id >= 0].any()
+    s.close()
+
+
+@pytest.mark.parametrize("count", [5, 9, 127, 128, 300])
+def test_leaf_larger_than_four_triangles(po, count):
+    """The reference keeps a node as one leaf when its partition fails (bvh.c:51-55), so leaves of any
+    size can occur; the packer splits them into chains of at most 127."""
+    rng = np.random.default_rng(count)
+    c = rng.uniform(-1, 1, size=(count, 1, 3)) * (1.2, 1.2, 0.6)
+    v = c + rng.uniform(-0.25, 0.25, size=(count, 3, 3))
+    tris = tri_rows(v, uv=rng.uniform(0, 1, size=(count, 6)).astype(np.float32))
+    lo, hi = bounds(tris)
+    nodes = node_array(po, [(lo, hi, -1, -1, 0, count)])
+    s, ms = scene_of(po, [(tris, nodes, checker())])
+    got, want = compare(po, s, ms, [po.Transform(po.vec3(0, 0, 0), po.vec3(0.2, 0.4, 0))], front_camera(po), po.default_light(), 96, 96)
+    assert (want.hit_id >= 0).sum() > 50
+    # the work is the reference's in reference-order mode: one triangle test per triangle of the leaf
+    full = s.render(front_camera(po), po.default_light(), [po.Transform(po.vec3(0, 0, 0), po.vec3(0.2, 0.4, 0))], 96, 96, full=True)
+    if count <= 127:
+        assert full["counters"] == want.counters
+    else:       # the chain's own links are extra box tests; the triangle tests are still the reference's
+        assert full["counters"]["tri_tests"] == want.counters["tri_tests"]
+        assert full["counters"]["slab_tests"] >= want.counters["slab_tests"]
+    s.close()
+
+
+def test_oversize_leaf_inside_a_tree(po):
+    rng = np.random.default_rng(21)
+    left = tri_rows(rng.uniform(-0.3, 0.3, size=(3, 3, 3)) + (-0.8, 0, 0))
+    right = tri_rows(rng.uniform(-0.4, 0.4, size=(140, 3, 3)) + (0.7, 0, 0.2))
+    tris = np.concatenate([left, right])
+    (llo, lhi), (rlo, rhi) = bounds(left), bounds(right)
+    nodes = node_array(po, [(np.minimum(llo, rlo), np.maximum(lhi, rhi), 1, 2, 0, 143), (llo, lhi, -1, -1, 0, 3), (rlo, rhi, -1, -1, 3, 140)])
+    s, ms = scene_of(po, [(tris, nodes, checker())])
+    compare(po, s, ms, [identity(po)], front_camera(po), po.default_light(), 128, 72)
+    compare(po, s, ms, [identity(po)], front_camera(po), po.default_light(), 128, 72, full=True)
+    s.close()
+
+
+def test_ties_within_a_leaf_between_siblings_and_between_meshes(po):
+    """Coincident triangles hit at exactly the same t.  The reference keeps the first one tested inside a
+    leaf (strict <, bvh.c:83-92), lets the right sibling replace the left one's hit (bvh.c:99-107 test with <=
+    through the closest_t update order), and the earlier mesh wins between meshes (scene.c:72-88).  Whatever
+    the rule, the product must reproduce the oracle's choice."""
+    a = [[-1, -1, 0], [1, -1, 0], [0, 1, 0]]
+    b = [[-0.5, -1, 0.5], [1.5, -1, 0.5], [0.5, 1, 0.5]]
+    # same leaf: indices 0 and 1 coincide
+    tris = tri_rows([a, a, b, b], uv=np.array([[0.1, 0.1, 0.2, 0.1, 0.1, 0.2], [0.8, 0.8, 0.9, 0.8, 0.8, 0.9],
+                                             [0.1, 0.8, 0.2, 0.8, 0.1, 0.9], [0.8, 0.1, 0.9, 0.1, 0.8, 0.2]], np.float32))
+    lo, hi = bounds(tris)
+    one_leaf = node_array(po, [(lo, hi, -1, -1, 0, 4)])
+    s, ms = scene_of(po, [(tris, one_leaf, checker())])
+    got, want = compare(po, s, ms, [identity(po)], front_camera(po), po.default_light(), 64, 64)
+    assert set(np.unique(want.hit_id[want.hit_id >= 0]).tolist()) <= {0, 2}      # first of each coincident pair
+    s.close()
+    # siblings: triangle 0 in the left leaf, its twin (index 1) in the right leaf
+    tris2 = tri_rows([a, a], uv=np.array([[0.1, 0.1, 0.2, 0.1, 0.1, 0.2], [0.8, 0.8, 0.9, 0.8, 0.8, 0.9]], np.float32))
+    lo, hi = bounds(tris2)
+    sib = node_array(po, [(lo, hi, 1, 2, 0, 2), (lo, hi, -1, -1, 0, 1), (lo, hi, -1, -1, 1, 1)])
+    s, ms = scene_of(po, [(tris2, sib, checker())])
+    got, want = compare(po, s, ms, [identity(po)], front_camera(po), po.default_light(), 64, 64)
+    compare(po, s, ms, [identity(po)], front_camera(po), po.default_light(), 64, 64, full=True)
+    assert len(np.unique(want.hit_id[want.hit_id >= 0])) == 1
+    s.close()
+    # two meshes with the same geometry and placement
+    s, ms = scene_of(po, [(tris2[:1], one_leaf_of(po, tris2[:1]), checker()), (tris2[1:], one_leaf_of(po, tris2[1:]), checker(4))])
+    got, want = compare(po, s, ms, [identity(po), identity(po)], front_camera(po), po.default_light(), 64, 64)
+    assert set(np.unique(want.hit_id[want.hit_id >= 0] >> 24).tolist()) == {0}
+    s.close()
+
+
+def one_leaf_of(po, tris):
+    lo, hi = bounds(tris)
+    return node_array(po, [(lo, hi, -1, -1, 0, tris.shape[0])])
+
+
+def test_many_coincident_triangles_in_a_real_build(po):
+    """Every triangle twice: the reference's builder puts equal centroids on the same side, so twins share
+    leaves or end up in leaves that could not be split."""
+    rng = np.random.default_rng(33)
+    base = tri_rows(rng.uniform(-0.2, 0.2, size=(60, 3, 3)) + rng.uniform(-1, 1, size=(60, 1, 3)) * (1.3, 1.0, 0.3),
+                    uv=rng.uniform(0, 1, size=(60, 6)).astype(np.float32))
+    post, nodes = po.build_bvh(np.concatenate([base, base]))
+    s, ms = scene_of(po, [(post, nodes, checker())])
+    compare(po, s, ms, [po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0.5, 0.1))], front_camera(po), po.default_light(), 128, 96)
+    compare(po, s, ms, [po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0.5, 0.1))], front_camera(po), po.default_light(), 128, 96, full=True)
+    s.close()
+
+
+def test_degenerate_and_edge_on_triangles(po):
+    v = [[[0, 0, 0], [0, 0, 0], [0, 0, 0]],                    # a point
+         [[-1, 0, 0], [1, 0, 0], [0, 0, 0]],                   # collinear
+         [[-1, -1, 0], [1, -1, 0], [0, 1, 0]],
+         [[0, -1, -1], [0, -1, 1], [0, 1, 0]],                 # edge-on to the camera axis
+         [[-1, 0.5, 0.5], [1, 0.5, 0.5], [0, 0.5, -1]]]        # edge-on horizontally
+    tris = tri_rows(v)
+    tris[:2, 15:24] = 0.0
+    s, ms = scene_of(po, [(tris, one_leaf_of(po, tris), checker())])
+    compare(po, s, ms, [identity(po)], front_camera(po), po.default_light(), 80, 80)
+    cam = po.Camera(po.vec3(0, 0.5, -4), po.vec3(0, 0.5, 0), po.vec3(0, 1, 0), 40.0)
+    compare(po, s, ms, [identity(po)], cam, po.default_light(), 81, 81)
+    s.close()
+
+
+def test_malformed_trees_are_rejected_with_a_message(po):
+    tris = tri_rows(np.random.default_rng(1).uniform(-1, 1, size=(6, 3, 3)))
+    lo, hi = bounds(tris)
+    bad = {
+        "internal node with a single child": [(lo, hi, 1, -1, 0, 6), (lo, hi, -1, -1, 0, 6)],
+        "node index out of range": [(lo, hi, 1, 7, 0, 6), (lo, hi, -1, -1, 0, 3)],
+        "leaf triangle range out of bounds": [(lo, hi, -1, -1, 2, 6)],
+        "triangle referenced by two leaves": [(lo, hi, 1, 2, 0, 6), (lo, hi, -1, -1, 0, 4), (lo, hi, -1, -1, 3, 3)],
+        "node reachable twice": [(lo, hi, 1, 1, 0, 6), (lo, hi, -1, -1, 0, 6)],
+    }
+    for msg, rows in bad.items():
+        s = emul.Scene()
+        st = s.add(tris, node_array(po, rows), checker())
+        assert st < 0 and msg in s.error(), (msg, st, s.error())
+        s.close()
+
+
+def test_tree_deeper_than_the_stack_is_rejected(po):
+    n = 45
+    rng = np.random.default_rng(2)
+    tris = tri_rows(rng.uniform(-0.1, 0.1, size=(n, 3, 3)) + np.linspace(-2, 2, n)[:, None, None] * np.array([1, 0, 0]))
+    rows = []
+    for i in range(n - 1):                                  # node 2i: internal; node 2i+1: leaf with triangle i
+        lo, hi = bounds(tris[i:])
+        rows.append((lo, hi, 2 * i + 1, 2 * i + 2, i, n - i))
+        rows.append((*bounds(tris[i:i + 1]), -1, -1, i, 1))
+    rows.append((*bounds(tris[n - 1:]), -1, -1, n - 1, 1))
+    s = emul.Scene()
+    st = s.add(tris, node_array(po, rows), checker())
+    assert st < 0 and "deeper" in s.error()
+    s.close()
+    # the same chain cut to the supported depth renders correctly
+    n2 = 29
+    rows2 = []
+    for i in range(n2 - 1):
+        lo, hi = bounds(tris[i:n2])
+        rows2.append((lo, hi, 2 * i + 1, 2 * i + 2, i, n2 - i))
+        rows2.append((*bounds(tris[i:i + 1]), -1, -1, i, 1))
+    rows2.append((*bounds(tris[n2 - 1:n2]), -1, -1, n2 - 1, 1))
+    s, ms = scene_of(po, [(tris[:n2], node_array(po, rows2), checker())])
+    assert s.info(0)["depth"] == n2 - 1
+    got, _ = compare(po, s, ms, [identity(po)], front_camera(po), po.default_light(), 160, 40)
+    compare(po, s, ms, [identity(po)], front_camera(po), po.default_light(), 160, 40, full=True)
+    s.close()
+
+
+def test_priorities_encode_the_reference_tie_order(po, meshes, em_default):
+    """Inside one leaf the lower index wins, so its priority is higher; priorities are unique per mesh."""
+    for mi, m in enumerate(meshes):
+        pr = em_default.prios(mi, m.tris.shape[0])
+        assert len(np.unique(pr)) == pr.size
+        leaves = m.nodes[m.nodes["left"] < 0]
+        for s0, c in zip(leaves["start"], leaves["count"]):
+            assert (np.diff(pr[s0:s0 + c].astype(np.int64)) < 0).all()

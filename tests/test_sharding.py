@@ -1,0 +1,138 @@
+"""Frame sharding and the framebuffer gather, on CPU tensors with the gloo backend (two and three
+processes).  The frames are produced by the CPU oracle here -- the subject of the test is the
+distribution logic, which is the same code that runs over RCCL on GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def test_frames_for_rank_partitions_the_animation():
+    from raytracer_amd.sharding import frames_for_rank, owner_of
+    for n in (0, 1, 7, 96):
+        for world in (1, 2, 3, 8):
+            shares = [frames_for_rank(n, r, world) for r in range(world)]
+            assert sorted(f for s in shares for f in s) == list(range(n))
+            assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
+            for r, s in enumerate(shares):
+                assert all(owner_of(f, world) == r for f in s)
+    with pytest.raises(ValueError):
+        frames_for_rank(10, 2, 2)
+    with pytest.raises(ValueError):
+        frames_for_rank(10, 0, 0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, batch, w, h, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      OMP_NUM_THREADS="2")
+    import torch
+    import torch.distributed as dist
+    from oracle import pyoracle as po
+    from raytracer_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    meshes = po.default_meshes()
+    cam, light = po.default_camera(), po.default_light()
+    rendered = []
+
+    def render_one(frame, out):
+        fr = po.render_frame(meshes, po.animation_transforms(frame), cam, light, w, h, threads=2, debug=False)
+        out.copy_(torch.from_numpy(fr.rgb))
+        rendered.append(frame)
+
+    frames = sharding.render_sharded(n_frames, rank, world, h, w, render_one, torch.device("cpu"), batch=batch)
+    assert rendered == sharding.frames_for_rank(n_frames, rank, world)
+    if rank == 0:
+        assert sorted(frames) == list(range(n_frames))
+        np.save(os.path.join(out_dir, "gathered.npy"), np.stack([frames[f].numpy() for f in range(n_frames)]))
+    else:
+        assert frames is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames,batch", [(2, 7, 2), (2, 4, 4), (3, 5, 1)])
+def test_sharded_render_gathers_every_frame_on_rank0(tmp_path, po, meshes, world, n_frames, batch):
+    import torch.multiprocessing as mp
+    w, h = 48, 27
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, batch, w, h, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("a rank did not finish")
+        assert p.exitcode == 0
+    got = np.load(os.path.join(tmp_path, "gathered.npy"))
+    assert got.shape == (n_frames, h, w, 3)
+    for f in range(n_frames):
+        want = po.render_frame(meshes, po.animation_transforms(f), po.default_camera(), po.default_light(), w, h, debug=False)
+        assert np.array_equal(got[f], want.rgb), f"frame {f}"
+
+
+def _gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.sharding import FrameGather
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = FrameGather(rank, world)
+    like = torch.zeros((2, 4, 5, 3), dtype=torch.uint8)
+    g.prealloc(3, like)
+    sent = []
+    for i in range(3):                                  # several submits in flight before finish()
+        t = torch.full((2, 4, 5, 3), 10 * rank + i, dtype=torch.uint8)
+        sent.append(t)
+        g.submit(t)
+    got = g.finish()
+    if rank == 0:
+        assert len(got) == 3
+        for i, per in enumerate(got):
+            assert len(per) == world
+            for r, t in enumerate(per):
+                assert (t == 10 * r + i).all()
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_gather_keeps_submit_order_with_several_in_flight(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert os.path.exists(os.path.join(tmp_path, "ok"))
+
+
+def test_frame_gather_single_rank_is_a_passthrough():
+    import torch
+    from raytracer_amd.sharding import FrameGather
+    g = FrameGather(0, 1)
+    t = torch.arange(24, dtype=torch.uint8).reshape(1, 2, 4, 3)
+    g.submit(t)
+    out = g.finish()
+    assert len(out) == 1 and out[0][0] is t
