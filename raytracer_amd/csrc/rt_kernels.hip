@@ -26,11 +26,18 @@ namespace rt {
 template <int BLOCK>
 struct LdsStack {
     uint32_t* base;      // &stack_area[threadIdx.x]
-    int sp;
-    __device__ __forceinline__ void clear() { sp = 0; }
-    __device__ __forceinline__ bool empty() const { return sp == 0; }
-    __device__ __forceinline__ void push(uint32_t v) { base[sp * BLOCK] = v; sp++; }
-    __device__ __forceinline__ uint32_t pop() { sp--; return base[sp * BLOCK]; }
+    uint32_t* top;       // next free entry: base + entries * BLOCK
+    __device__ __forceinline__ void init(uint32_t* b) { base = b; top = b; }
+    __device__ __forceinline__ void clear() { top = base; }
+    __device__ __forceinline__ bool empty() const { return top == base; }
+    __device__ __forceinline__ void push(uint32_t v) { *top = v; top += BLOCK; }
+    __device__ __forceinline__ uint32_t pop() { top -= BLOCK; return *top; }
+    // push(a) if `any`, then push(b) if `both` (both implies any)
+    __device__ __forceinline__ void push2(uint32_t a, bool any, uint32_t b, bool both) {
+        if (any) top[0] = a;
+        if (both) top[BLOCK] = b;
+        top += (any ? BLOCK : 0) + (both ? BLOCK : 0);
+    }
 };
 
 // PairNodes staged in LDS.
@@ -87,8 +94,7 @@ template <int BLOCK, bool COUNT, bool FULL>
 __global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const SceneArgs S, const OutputPlanes O) {
     __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
     LdsStack<BLOCK> stack;
-    stack.base = &lds_stack[threadIdx.x];
-    stack.sp = 0;
+    stack.init(&lds_stack[threadIdx.x]);
     GlobalNodes nodes; nodes.all = S.pairs;
 
     const int tiles_x = (A.width + 7) >> 3;
@@ -161,8 +167,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) render_lean(const FrameArgs A, co
         __syncthreads();
     }
     LdsStack<BLOCK> stack;
-    stack.base = &lds_stack[threadIdx.x];
-    stack.sp = 0;
+    stack.init(&lds_stack[threadIdx.x]);
     HybridNodes nodes; nodes.global_all = S.pairs; nodes.lds = reinterpret_cast<const uint8_t*>(lds_blob);
     const int tiles_x = (A.width + 7) >> 3;
     const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -208,8 +213,7 @@ __global__ void __launch_bounds__(BLOCK) render_batch(const FrameArgs* __restric
                                                       const int first_row) {
     __shared__ uint32_t lds_stack[DEPTH * BLOCK];
     LdsStack<BLOCK> stack;
-    stack.base = &lds_stack[threadIdx.x];
-    stack.sp = 0;
+    stack.init(&lds_stack[threadIdx.x]);
     GlobalNodes nodes; nodes.all = S.pairs;
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)));
@@ -424,7 +428,7 @@ __global__ void __launch_bounds__(BLOCK) render_tiles(const FrameArgs A, const S
             CoopGroup<BLOCK> party;
             party.lane = (uint32_t)lane;
             party.area = &lds_stack[threadIdx.x & ~7u];
-            LdsStack<BLOCK> unused_stack; unused_stack.base = nullptr; unused_stack.sp = 0;
+            LdsStack<BLOCK> unused_stack; unused_stack.init(nullptr);
             Work work; work.slabs = 0; work.tris = 0;
             const PixelOut r = shade_pixel<false, false, false>(A, nodes, party, px, py, unused_stack, work);
             if ((lane & 7) == 0) store_pixel(O, A.width, px, py, r);
@@ -437,8 +441,7 @@ __global__ void __launch_bounds__(BLOCK) render_tiles(const FrameArgs A, const S
         const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
         if (px < A.width && py < A.height) {
             LdsStack<BLOCK> stack;
-            stack.base = &lds_stack[threadIdx.x];
-            stack.sp = 0;
+            stack.init(&lds_stack[threadIdx.x]);
             Work work; work.slabs = 0; work.tris = 0;
             const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work);
             store_pixel(O, A.width, px, py, r);
@@ -486,8 +489,7 @@ __global__ void __launch_bounds__(BLOCK) render_pass1(const FrameArgs A, const S
     __syncthreads();
 
     LdsStack<BLOCK> stack;
-    stack.base = &lds_stack[threadIdx.x];
-    stack.sp = 0;
+    stack.init(&lds_stack[threadIdx.x]);
     GlobalNodes nodes; nodes.all = S.pairs;
 
     const int lane = threadIdx.x & 63;
@@ -541,7 +543,7 @@ __global__ void __launch_bounds__(kPass2Block) render_pass2(const FrameArgs A, c
     CoopGroup<kPass2Block> party;
     party.lane = (uint32_t)lane;
     party.area = &lds_stack[threadIdx.x & ~7u];
-    LdsStack<kPass2Block> unused_stack; unused_stack.base = nullptr; unused_stack.sp = 0;
+    LdsStack<kPass2Block> unused_stack; unused_stack.init(nullptr);
     for (uint32_t b = wave; b < n_batches; b += total_waves) {     // b is uniform over the wave
         const uint32_t at = b * kGroupLanes + (uint32_t)(lane >> 3);
         if (at < n) {
@@ -593,8 +595,7 @@ __global__ void __launch_bounds__(kResidentBlock) render_resident(const FrameArg
     __syncthreads();
 
     LdsStack<kResidentBlock> stack;
-    stack.base = &lds_stack[threadIdx.x];
-    stack.sp = 0;
+    stack.init(&lds_stack[threadIdx.x]);
     LdsNodes nodes; nodes.all = lds_nodes;
 
     const int lane = threadIdx.x & 63;

@@ -59,6 +59,48 @@ RT_HD bool beats(bool a_found, const Hit& a, bool b_found, const Hit& b) {
 
 constexpr uint32_t kLeafBatch = 4;       // triangles fetched together in a leaf
 
+// Slab tests of both children of a PairNode (aabb.c:33-56 twice), entry distances reported.
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device form: the 24 subtractions and multiplications run as 12 two-wide packed operations
+// (v_pk_add_f32 / v_pk_mul_f32 round each half exactly like the scalar instructions).  The twelve
+// bounds are taken as six register pairs in memory order -- (lmin.x,lmin.y) (lmin.z,lmax.x)
+// (lmax.y,lmax.z) and the same for the right box -- against matching pairs of the ray's origin and
+// reciprocal direction.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct SlabRay {
+    v2f oxy, ozx, oyz, ixy, izx, iyz;
+};
+RT_HD SlabRay slab_ray(F3 o, F3 inv) {
+    SlabRay r;
+    r.oxy = v2f{o.x, o.y}; r.ozx = v2f{o.z, o.x}; r.oyz = v2f{o.y, o.z};
+    r.ixy = v2f{inv.x, inv.y}; r.izx = v2f{inv.z, inv.x}; r.iyz = v2f{inv.y, inv.z};
+    return r;
+}
+RT_HD bool slab_half(v2f p0, v2f p1, v2f p2, const SlabRay& r, float& entry) {
+    const v2f a0 = (p0 - r.oxy) * r.ixy;        // min.x, min.y
+    const v2f a1 = (p1 - r.ozx) * r.izx;        // min.z, max.x
+    const v2f a2 = (p2 - r.oyz) * r.iyz;        // max.y, max.z
+    float tmin = fminf(a0.x, a1.y), tmax = fmaxf(a0.x, a1.y);
+    tmin = fmaxf(tmin, fminf(a0.y, a2.x)); tmax = fminf(tmax, fmaxf(a0.y, a2.x));
+    tmin = fmaxf(tmin, fminf(a1.x, a2.y)); tmax = fminf(tmax, fmaxf(a1.x, a2.y));
+    entry = tmin;
+    return tmax >= tmin && tmax > 0;
+}
+RT_HD void slab_pair(const SlabRay& r, const PairNode& N, float& tl, float& tr, bool& hl, bool& hr) {
+    hl = slab_half(v2f{N.lmin[0], N.lmin[1]}, v2f{N.lmin[2], N.lmax[0]}, v2f{N.lmax[1], N.lmax[2]}, r, tl);
+    hr = slab_half(v2f{N.rmin[0], N.rmin[1]}, v2f{N.rmin[2], N.rmax[0]}, v2f{N.rmax[1], N.rmax[2]}, r, tr);
+}
+#else
+struct SlabRay {
+    F3 o, inv;
+};
+RT_HD SlabRay slab_ray(F3 o, F3 inv) { SlabRay r; r.o = o; r.inv = inv; return r; }
+RT_HD void slab_pair(const SlabRay& r, const PairNode& N, float& tl, float& tr, bool& hl, bool& hr) {
+    hl = slab_t(r.o, r.inv, N.lmin, N.lmax, tl);
+    hr = slab_t(r.o, r.inv, N.rmin, N.rmax, tr);
+}
+#endif
+
 // State of one closest-hit / any-hit query while it runs.
 struct Query {
     float best_t;        // bvh.c:85 / bvh.c:106: bound of the leaf tests
@@ -136,6 +178,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
     if (!begin_query<ANY, COUNT, FULL>(M, o, inv, bound, q, work)) return false;
     stack.clear();
     stack.push(M.root_ref);
+    const SlabRay sr = slab_ray(o, inv);
     while (!stack.empty()) {
         if (BUDGET && --steps < 0) return false;
         const uint32_t ref = stack.pop();
@@ -145,16 +188,15 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
             const PairNode N = nodes(M, ref);
             if (COUNT) work.slabs += 2;
             float tl, tr;
-            bool hl = slab_t(o, inv, N.lmin, N.lmax, tl);
-            bool hr = slab_t(o, inv, N.rmin, N.rmax, tr);
+            bool hl, hr;
+            slab_pair(sr, N, tl, tr, hl, hr);
             if (CULL) {
                 hl = hl && !(tl > q.limit);
                 hr = hr && !(tr > q.limit);
-                const bool left_first = !(tr < tl);                    // nearer child is popped first
-                const uint32_t far_ref = left_first ? N.rref : N.lref, near_ref = left_first ? N.lref : N.rref;
-                const bool far_hit = left_first ? hr : hl, near_hit = left_first ? hl : hr;
-                if (far_hit) stack.push(far_ref);
-                if (near_hit) stack.push(near_ref);
+                // Nearer child on top: with both children pending the farther one goes in first.
+                const bool left_first = !(tr < tl);
+                const bool first_is_right = hr && (!hl || left_first);
+                stack.push2(first_is_right ? N.rref : N.lref, hl || hr, left_first ? N.lref : N.rref, hl && hr);
             } else {
                 if (hr) stack.push(N.rref);
                 if (hl) stack.push(N.lref);
