@@ -143,6 +143,22 @@ int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* l
                          int32_t width, int32_t height, uint32_t flags,
                          uint8_t* h_rgb, int32_t* h_hit_id, float* h_hit_t, uint8_t* h_shadow);
 
+/* ---- encoder-side upscale -------------------------------------------------------------- */
+/* Output size save_scene derives from the scene (scene.c:164-165): (int)(size / scale_factor + 0.5f). */
+int rt_scaled_size(int32_t width, int32_t height, float scale_factor, int32_t* scaled_width, int32_t* scaled_height);
+
+/* The bicubic upscale loop of save_scene (scene.c:188-202, bicubic_interpolate utils/image.c:25-78) for
+ * n_frames frames: RGB8 frame f at (uint8_t*)d_rgb + f*frame_stride (bytes; the layout rt_render_frames
+ * writes) becomes the ARGB32 image WebPPicture.argb holds, 0xFF000000 | r<<16 | g<<8 | b, row-major
+ * scaled_width x scaled_height, at (uint32_t*)d_argb + f*out_stride (out_stride in PIXELS, >=
+ * scaled_width*scaled_height).  scaled sizes must be >= 2.  Asynchronous on `stream`. */
+int rt_upscale_frames(rt_ctx* ctx, const void* d_rgb, size_t frame_stride, int32_t n_frames,
+                      int32_t width, int32_t height, int32_t scaled_width, int32_t scaled_height,
+                      void* d_argb, size_t out_stride, void* stream);
+/* Same for one frame in host memory: copies in, upscales, waits, copies out. */
+int rt_upscale_frame_host(rt_ctx* ctx, const uint8_t* h_rgb, int32_t width, int32_t height,
+                          int32_t scaled_width, int32_t scaled_height, uint32_t* h_argb);
+
 int rt_sync(rt_ctx* ctx, void* stream);                           /* waits for all launches on stream */
 /* GPU time of the most recent rt_render_frame launch, from HIP events recorded on its stream
  * (waits for that launch). */

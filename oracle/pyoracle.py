@@ -115,6 +115,10 @@ def lib():
         L.orc_sample_texture.argtypes = [C.POINTER(Mesh), C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.orc_bicubic.restype = C.c_uint32
         L.orc_bicubic.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.orc_scaled_size.restype = None
+        L.orc_scaled_size.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_upscale_frame.restype = None
+        L.orc_upscale_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int32]
         L.orc_mesh_matrices.restype = None
         L.orc_mesh_matrices.argtypes = [Transform, C.c_void_p, C.c_void_p]
         L.orc_build_bvh.restype = C.c_int32
@@ -167,6 +171,8 @@ def ref():
         R.refc_make_light.argtypes = [C.POINTER(Vec3), C.POINTER(Vec3), C.POINTER(Light)]
         R.refc_bicubic.restype = C.c_uint32
         R.refc_bicubic.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int]
+        R.refc_upscale_frame.restype = None
+        R.refc_upscale_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         R.refc_render_frame.restype = None
         R.refc_render_frame.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Transform), C.c_int, C.POINTER(Camera), C.POINTER(Light),
                                         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -290,6 +296,23 @@ def render_frame(meshes: Sequence[HostMesh], transforms: Sequence[Transform], ca
                            _ptr(hid) if debug else None, _ptr(ht) if debug else None, _ptr(sh) if debug else None,
                            C.byref(cnt), threads)
     return Frame(rgb, hid, ht, sh, cnt.as_dict())
+
+
+def scaled_size(width: int, height: int, scale_factor: float):
+    """Output size of the encoder's upscale (scene.c:164-165)."""
+    sw, sh = C.c_int(0), C.c_int(0)
+    lib().orc_scaled_size(width, height, scale_factor, C.byref(sw), C.byref(sh))
+    return sw.value, sh.value
+
+
+def upscale_frame(rgb: np.ndarray, scaled_width: int, scaled_height: int, threads: int = 0, use_ref: bool = False) -> np.ndarray:
+    """The bicubic upscale of one RGB8 frame to ARGB uint32 [scaled_height, scaled_width] (scene.c:188-202)."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    out = np.zeros((scaled_height, scaled_width), np.uint32)
+    fn = ref().refc_upscale_frame if use_ref else lib().orc_upscale_frame
+    fn(_ptr(rgb), w, h, scaled_width, scaled_height, _ptr(out), threads)
+    return out
 
 
 class RefScene:

@@ -94,6 +94,22 @@ uint32_t refc_bicubic(const uint8_t* frame, float x, float y, int w, int h) {
     return bicubic_interpolate((unsigned char*)frame, x, y, w, h);
 }
 
+/* The upscale loop of save_scene (scene.c:188-202) around the reference's bicubic_interpolate. */
+void refc_upscale_frame(const uint8_t* frame, int width, int height, int scaled_width, int scaled_height,
+                        uint32_t* argb, int threads) {
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#endif
+    #pragma omp parallel for schedule(static) num_threads(threads)
+    for (int y = 0; y < scaled_height; y++) {
+        for (int x = 0; x < scaled_width; x++) {
+            float src_x = x * (width - 1.0f) / (scaled_width - 1.0f);
+            float src_y = y * (height - 1.0f) / (scaled_height - 1.0f);
+            argb[(size_t)y * scaled_width + x] = bicubic_interpolate((unsigned char*)frame, src_x, src_y, width, height);
+        }
+    }
+}
+
 void refc_render_frame(RefMesh* const* meshes, const Transform* tfs, int mesh_count, const Camera* cam,
                        const DirectionalLight* light, int width, int height, uint8_t* rgb,
                        int32_t* hit_id, float* hit_t, uint8_t* shadow, int threads) {

@@ -368,6 +368,28 @@ uint32_t orc_bicubic(const uint8_t* frame, float x, float y, int width, int heig
     return out;
 }
 
+/* Output size of the encoder's upscale (scene.c:164-165). */
+void orc_scaled_size(int width, int height, float scale_factor, int* scaled_width, int* scaled_height) {
+    *scaled_width = (int)(width / scale_factor + 0.5f);
+    *scaled_height = (int)(height / scale_factor + 0.5f);
+}
+
+/* One frame through the bicubic upscale loop (scene.c:188-202): ARGB, row-major. */
+void orc_upscale_frame(const uint8_t* frame, int width, int height, int scaled_width, int scaled_height,
+                       uint32_t* argb, int32_t threads) {
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#endif
+    #pragma omp parallel for schedule(static) num_threads(threads)
+    for (int y = 0; y < scaled_height; y++) {
+        for (int x = 0; x < scaled_width; x++) {
+            float src_x = x * (width - 1.0f) / (scaled_width - 1.0f);      /* scene.c:191 */
+            float src_y = y * (height - 1.0f) / (scaled_height - 1.0f);    /* scene.c:192 */
+            argb[(size_t)y * scaled_width + x] = orc_bicubic(frame, src_x, src_y, width, height);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ the frame loop (scene.c:52-160) */
 void orc_render_frame(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* light,
                       int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_id, float* hit_t,

@@ -77,6 +77,9 @@ int    orc_intersect_bvh(const ONode* nodes, int32_t node, ORay ray, const OTria
 OLight orc_make_light(OVec3 direction, OVec3 color);
 void   orc_sample_texture(const OMesh* mesh, float u, float v, float rgb[3]);
 uint32_t orc_bicubic(const uint8_t* frame, float x, float y, int width, int height);
+void   orc_scaled_size(int width, int height, float scale_factor, int* scaled_width, int* scaled_height);
+void   orc_upscale_frame(const uint8_t* frame, int width, int height, int scaled_width, int scaled_height,
+                         uint32_t* argb, int32_t threads);
 
 /* Per-frame constants of one mesh placement, exactly as transform_ray / transform_normal
  * derive them for every ray: inv = inverse(T*Rz*Ry*Rx), nrm = transpose(inverse(Rz*Ry*Rx)). */

@@ -55,7 +55,7 @@ EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_bvh_build", "rt_bvh_flatten_tree",
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
-    "rt_set_trace_buffer", "rt_render_frames",
+    "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
 ]
 
 _lib = None
@@ -104,6 +104,9 @@ def lib():
                                            vp, vp, vp, vp]
         L.rt_render_frames.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, i32,
                                        vp, C.c_size_t, vp]
+        L.rt_scaled_size.argtypes = [i32, i32, C.c_float, C.POINTER(i32), C.POINTER(i32)]
+        L.rt_upscale_frames.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
+        L.rt_upscale_frame_host.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.rt_sync.argtypes = [vp, vp]
         L.rt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.rt_last_counters.argtypes = [vp, C.POINTER(Counters)]
@@ -118,6 +121,15 @@ def lib():
 
 def status_string(status: int) -> str:
     return lib().rt_status_string(status).decode()
+
+
+def scaled_size(width: int, height: int, scale_factor: float):
+    """rt_scaled_size: the upscaled size save_scene derives (scene.c:164-165)."""
+    sw, sh = C.c_int32(0), C.c_int32(0)
+    st = lib().rt_scaled_size(int(width), int(height), float(scale_factor), C.byref(sw), C.byref(sh))
+    if st != RT_OK:
+        raise RtError(st)
+    return sw.value, sh.value
 
 
 def build_bvh(tris: np.ndarray):
@@ -241,6 +253,22 @@ class Context:
                                                hid.ctypes.data if debug else None, ht.ctypes.data if debug else None,
                                                sh.ctypes.data if debug else None))
         return rgb, hid, ht, sh
+
+    def upscale_frames(self, rgb, n_frames: int, width: int, height: int, scaled_width: int, scaled_height: int, argb,
+                       frame_stride: Optional[int] = None, out_stride: Optional[int] = None, stream: Optional[int] = None):
+        """rt_upscale_frames on device buffers: rgb [n, h, w, 3] uint8 -> argb [n, sh, sw] 32-bit."""
+        fs = int(frame_stride) if frame_stride is not None else int(width) * int(height) * 3
+        os_ = int(out_stride) if out_stride is not None else int(scaled_width) * int(scaled_height)
+        self._check(lib().rt_upscale_frames(self._h, _dev_ptr(rgb), fs, int(n_frames), int(width), int(height),
+                                            int(scaled_width), int(scaled_height), _dev_ptr(argb), os_, stream))
+
+    def upscale_host(self, rgb: np.ndarray, scaled_width: int, scaled_height: int) -> np.ndarray:
+        """rt_upscale_frame_host: numpy [h, w, 3] uint8 -> numpy [sh, sw] uint32 (ARGB)."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        out = np.zeros((int(scaled_height), int(scaled_width)), np.uint32)
+        self._check(lib().rt_upscale_frame_host(self._h, rgb.ctypes.data, int(rgb.shape[1]), int(rgb.shape[0]),
+                                                int(scaled_width), int(scaled_height), out.ctypes.data))
+        return out
 
     def set_trace_buffer(self, buf):
         """Per-tile {start, end} clock trace into a device buffer of 2 uint64 per 8x8 tile (None = off)."""

@@ -54,6 +54,9 @@ struct rt_ctx {
     // planes used by rt_render_frame_host
     uint8_t* d_rgb = nullptr; int32_t* d_id = nullptr; float* d_t = nullptr; uint8_t* d_shadow = nullptr;
     size_t plane_pixels = 0;
+    // buffers of rt_upscale_frame_host
+    uint8_t* d_up_in = nullptr; uint32_t* d_up_out = nullptr;
+    size_t up_in_bytes = 0, up_out_pixels = 0;
     LaunchConfig cfg;
     int timing = 1;
     int budget = 48;               // two-pass variant: node visits per pixel before it is deferred
@@ -284,6 +287,8 @@ int rt_ctx_destroy(rt_ctx* ctx) {
     if (ctx->d_id) (void)hipFree(ctx->d_id);
     if (ctx->d_t) (void)hipFree(ctx->d_t);
     if (ctx->d_shadow) (void)hipFree(ctx->d_shadow);
+    if (ctx->d_up_in) (void)hipFree(ctx->d_up_in);
+    if (ctx->d_up_out) (void)hipFree(ctx->d_up_out);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -505,6 +510,59 @@ int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* l
     if (h_hit_id) RT_HIP(ctx, hipMemcpy(h_hit_id, ctx->d_id, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (h_hit_t) RT_HIP(ctx, hipMemcpy(h_hit_t, ctx->d_t, pixels * sizeof(float), hipMemcpyDeviceToHost));
     if (h_shadow) RT_HIP(ctx, hipMemcpy(h_shadow, ctx->d_shadow, pixels, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_scaled_size(int32_t width, int32_t height, float scale_factor, int32_t* scaled_width, int32_t* scaled_height) {
+    if (!scaled_width || !scaled_height || width <= 0 || height <= 0 || !(scale_factor > 0.0f)) return RT_ERR_INVALID;
+    *scaled_width = (int32_t)((float)width / scale_factor + 0.5f);
+    *scaled_height = (int32_t)((float)height / scale_factor + 0.5f);
+    return RT_OK;
+}
+
+int rt_upscale_frames(rt_ctx* ctx, const void* d_rgb, size_t frame_stride, int32_t n_frames, int32_t width, int32_t height,
+                      int32_t scaled_width, int32_t scaled_height, void* d_argb, size_t out_stride, void* stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!d_rgb || !d_argb) return fail(ctx, RT_ERR_INVALID, "d_rgb and d_argb are required");
+    if (n_frames < 1 || n_frames > 65535) return fail(ctx, RT_ERR_INVALID, "n_frames must be 1..65535");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    if (scaled_width < 2 || scaled_height < 2) return fail(ctx, RT_ERR_UNSUPPORTED, "scaled size must be at least 2x2");
+    if ((int64_t)scaled_width * scaled_height > (int64_t)1 << 30 || scaled_height > 65535 * 8) return fail(ctx, RT_ERR_UNSUPPORTED, "scaled size too large");
+    if (frame_stride < (size_t)width * (size_t)height * 3) return fail(ctx, RT_ERR_INVALID, "frame_stride smaller than one image");
+    if (out_stride < (size_t)scaled_width * (size_t)scaled_height) return fail(ctx, RT_ERR_INVALID, "out_stride smaller than one image");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
+    hipError_t le = launch_upscale((const uint8_t*)d_rgb, frame_stride, n_frames, width, height, scaled_width, scaled_height,
+                                   (uint32_t*)d_argb, out_stride, s);
+    if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
+    if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
+    return RT_OK;
+}
+
+int rt_upscale_frame_host(rt_ctx* ctx, const uint8_t* h_rgb, int32_t width, int32_t height, int32_t scaled_width,
+                          int32_t scaled_height, uint32_t* h_argb) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!h_rgb || !h_argb) return fail(ctx, RT_ERR_INVALID, "h_rgb and h_argb are required");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    if (scaled_width < 2 || scaled_height < 2) return fail(ctx, RT_ERR_UNSUPPORTED, "scaled size must be at least 2x2");
+    if ((int64_t)scaled_width * scaled_height > (int64_t)1 << 30) return fail(ctx, RT_ERR_UNSUPPORTED, "scaled size too large");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = (size_t)width * (size_t)height * 3, out_pixels = (size_t)scaled_width * (size_t)scaled_height;
+    if (in_bytes > ctx->up_in_bytes || out_pixels > ctx->up_out_pixels) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_up_in) (void)hipFree(ctx->d_up_in);
+        if (ctx->d_up_out) (void)hipFree(ctx->d_up_out);
+        ctx->d_up_in = nullptr; ctx->d_up_out = nullptr; ctx->up_in_bytes = 0; ctx->up_out_pixels = 0;
+        RT_HIP(ctx, hipMalloc((void**)&ctx->d_up_in, in_bytes));
+        RT_HIP(ctx, hipMalloc((void**)&ctx->d_up_out, out_pixels * sizeof(uint32_t)));
+        ctx->up_in_bytes = in_bytes; ctx->up_out_pixels = out_pixels;
+    }
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_up_in, h_rgb, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    int st = rt_upscale_frames(ctx, ctx->d_up_in, in_bytes, 1, width, height, scaled_width, scaled_height, ctx->d_up_out, out_pixels, nullptr);
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, hipMemcpyAsync(h_argb, ctx->d_up_out, out_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 

@@ -39,4 +39,10 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
 hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb, size_t frame_stride,
                         int first_row, int block, hipStream_t stream);
 
+// Enqueues the bicubic upscale of n_frames RGB8 frames (width x height, frame f at rgb + f*frame_stride
+// bytes) to ARGB32 frames (scaled_width x scaled_height, frame f at argb + f*out_stride pixels).
+// scaled sizes must be at least 2 (the source coordinate divides by scaled-1).
+hipError_t launch_upscale(const uint8_t* rgb, size_t frame_stride, int n_frames, int width, int height, int scaled_width,
+                          int scaled_height, uint32_t* argb, size_t out_stride, hipStream_t stream);
+
 }  // namespace rt

@@ -13,7 +13,11 @@
 //   2  render_resident with static tile assignment (wave w of W takes tiles w, w+W, ...).
 //   3  render_tiles    variant 0 plus cooperative rendering of the screen area of big meshes:
 //                      there a wave renders 8 pixels, each by 8 lanes that share the ray's
-//                      traversal stack, and those waves are launched first.  (Default.)
+//                      traversal stack, and those waves are launched first.
+//   4  render_pass1/2  two passes: one lane per pixel with a budget of node visits, then the pixels
+//                      that ran out of budget cooperatively (8 lanes per ray).
+//   5..9 render_lean   variant 0 with a short stack / other leaf batch sizes / occupancy hints.
+// rt_render_frames uses render_batch (several frames per launch), see below.
 #include <hip/hip_runtime.h>
 
 #include "rt_kernels.h"

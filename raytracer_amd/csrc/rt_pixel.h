@@ -17,10 +17,12 @@
 #include "rt_exact.h"
 #include "rt_layout.h"
 
+#ifndef RT_UNROLL
 #if defined(__HIPCC__) || defined(__clang__)
 #define RT_UNROLL _Pragma("unroll")
 #else
 #define RT_UNROLL _Pragma("GCC unroll 8")
+#endif
 #endif
 
 namespace rt {

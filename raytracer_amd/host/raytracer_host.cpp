@@ -369,6 +369,28 @@ void rt_host_demo_animation(int frame, Transform* drone, Transform* treasure) {
     }
 }
 
+int rt_host_scaled_size(const Scene* scene, int* scaled_width, int* scaled_height) {            // scene.c:164-165
+    if (!scene) return RT_ERR_INVALID;
+    return rt_scaled_size(scene->width, scene->height, scene->scale_factor, scaled_width, scaled_height);
+}
+
+int rt_host_upscale_frame(Scene* scene, int index, uint32_t* argb) {                             // scene.c:188-202
+    if (!scene || !argb || !scene->frames || index < 0 || index >= scene->frame_count) return RT_ERR_INVALID;
+    int sw = 0, sh = 0;
+    int rc = rt_host_scaled_size(scene, &sw, &sh);
+    if (rc != RT_OK) return rc;
+    std::lock_guard<std::mutex> g(g_lock);
+    SceneState* st = state_of(scene, true);
+    if (!st->ctx) {
+        rc = rt_ctx_create(pick_device(), &st->ctx);
+        if (rc != RT_OK) { fprintf(stderr, "rt_host_upscale_frame: cannot open GPU %d: %s\n", pick_device(), rt_status_string(rc)); st->last_status = rc; return rc; }
+    }
+    rc = rt_upscale_frame_host(st->ctx, scene->frames[index], scene->width, scene->height, sw, sh, argb);
+    if (rc != RT_OK) fprintf(stderr, "rt_host_upscale_frame: %s (%s)\n", rt_status_string(rc), rt_last_error(st->ctx));
+    st->last_status = rc;
+    return rc;
+}
+
 int rt_host_write_ppm(const Scene* scene, int index, const char* filename) {
     if (!scene || !filename || index < 0 || index >= scene->frame_count) return RT_ERR_INVALID;
     FILE* f = fopen(filename, "wb");

@@ -98,6 +98,10 @@ int rt_host_render_debug(Scene* scene, int32_t* hit_id, float* hit_t, uint8_t* s
 void rt_host_demo_animation(int frame, Transform* drone, Transform* treasure);
 /* Writes frame `index` as a binary PPM (P6). */
 int rt_host_write_ppm(const Scene* scene, int index, const char* filename);
+/* The size and the pixels save_scene hands to its encoder for one frame (scene.c:164-165, 188-202):
+ * argb receives scaled_width*scaled_height words, 0xFF000000 | r<<16 | g<<8 | b, upscaled on the GPU. */
+int rt_host_scaled_size(const Scene* scene, int* scaled_width, int* scaled_height);
+int rt_host_upscale_frame(Scene* scene, int index, uint32_t* argb);
 
 #ifdef __cplusplus
 }

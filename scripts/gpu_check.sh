@@ -29,4 +29,11 @@ echo "rocprof exit $rc4"
 find gpurun_out/prof -name '*kernel_stats*' | head -3
 f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && head -n 12 "$f"
+
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_upscale -o upscale -- python3 scripts/upscale_bench.py > gpurun_out/upscale_bench.json 2> gpurun_out/upscale.err
+rc5=$?
+echo "upscale rocprof exit $rc5"
+cat gpurun_out/upscale_bench.json | tail -n 1
+f=$(find gpurun_out/prof_upscale -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && head -n 4 "$f"
 exit $rc

@@ -55,8 +55,17 @@ def lib():
                                      C.POINTER(C.c_uint32)]
         L.emul_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32,
                                   vp, vp, vp, vp, C.POINTER(Counters), i32, vp, vp]
+        L.emul_upscale.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+        L.emul_upscale.restype = None
         _lib = L
     return _lib
+
+
+def upscale(rgb, scaled_width, scaled_height, rows=8):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    out = np.zeros((scaled_height, scaled_width), np.uint32)
+    lib().emul_upscale(rgb.ctypes.data, rgb.shape[1], rgb.shape[0], scaled_width, scaled_height, rows, out.ctypes.data)
+    return out
 
 
 def conv(obj, cls):

@@ -221,7 +221,10 @@ def test_device_buffers_async_and_deterministic(capi, ctx, po, golden_hashes):
 def test_reference_host_api_end_to_end(po, golden_hashes):
     """The reference driver's call sequence (raytracer.c:8-75) on the host API library."""
     import ctypes as C
+    import json
     import os
+    from conftest import GOLDEN
+    upscale_hashes = json.load(open(os.path.join(GOLDEN, "upscale_hashes.json")))
     from raytracer_amd import host_api as H
     L = H.lib()
     scene = L.create_scene(800, 600, 4000, 24, 0.9)
@@ -244,6 +247,12 @@ def test_reference_host_api_end_to_end(po, golden_hashes):
             L.render_scene(C.byref(scene))
             assert L.rt_host_last_status(C.byref(scene)) == 0
             assert sha(H.frame_array(scene, frame)) == golden_hashes["frames"][f"720x540_f{frame}"]["rgb"]
+            # what save_scene would hand to its encoder for this frame (scene.c:164-165, 188-202)
+            sw, sh = C.c_int(0), C.c_int(0)
+            assert L.rt_host_scaled_size(C.byref(scene), C.byref(sw), C.byref(sh)) == 0 and (sw.value, sh.value) == (800, 600)
+            argb = np.zeros((600, 800), np.uint32)
+            assert L.rt_host_upscale_frame(C.byref(scene), frame, argb.ctypes.data) == 0
+            assert sha(argb) == upscale_hashes[f"720x540_f{frame}_to_800x600"]["argb"]
         L.next_frame(C.byref(scene))
     for m in loaded:
         L.destroy_mesh(C.byref(m))
