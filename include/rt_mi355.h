@@ -176,7 +176,9 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * (threads per workgroup: 64, 128 or 256), "timing" (record HIP events around each launch, default 1),
  * "coop" (variant 3: 0 off, 1 cooperative tiles where primary or shadow rays can meet a big mesh,
  * 2 primary rays only), "budget" (variant 4: node visits one lane spends on a pixel before the pixel is
- * handed to the cooperative pass), "resident_budget" (variants 5..9: bytes of small meshes staged in LDS).
+ * handed to the cooperative pass), "resident_budget" (variants 5..9: bytes of small meshes staged in LDS),
+ * "batch_chunk" (rt_render_frames: consecutive tiles of one frame before the same tiles of the next
+ * frame; 0 = four tile rows).
  * Every setting produces the same image.  Read-only: "n_variants", "default_variant".
  * Unknown names give RT_ERR_INVALID. */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);

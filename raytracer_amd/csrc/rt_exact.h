@@ -152,6 +152,12 @@ RT_HD F3 xform_point(const float (*m)[4], const float* wrow, F3 p) {
               (m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3]) / w,
               (m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3]) / w);
 }
+// The same when the caller knows that w == 1.0f for every finite point (row 3 is 0 0 0 1): x / 1.0f is x.
+RT_HD F3 xform_point_w1(const float (*m)[4], F3 p) {
+    return f3(m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3],
+              m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3],
+              m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3]);
+}
 // mat4.c:71-77 on a [3][4] or [3][3] block.
 template <int STRIDE>
 RT_HD F3 xform_vector(const float (*m)[STRIDE], F3 v) {

@@ -35,9 +35,10 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
 
 // Enqueues n_frames frames of width x height in one launch.  d_frames is a device array of n_frames
 // FrameArgs (same size, flags 0), rgb receives frame f at rgb + f*frame_stride; tile rows are
-// scanned starting at first_row.  block: 64 or 256.
+// scanned starting at first_row; `chunk` consecutive tiles of a frame are followed by the same tiles
+// of the next frame.  block: 64 or 256.
 hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb, size_t frame_stride,
-                        int first_row, int block, hipStream_t stream);
+                        int first_row, int chunk, int block, hipStream_t stream);
 
 // Enqueues the bicubic upscale of n_frames RGB8 frames (width x height, frame f at rgb + f*frame_stride
 // bytes) to ARGB32 frames (scaled_width x scaled_height, frame f at argb + f*out_stride pixels).

@@ -36,12 +36,6 @@ struct LdsStack {
     __device__ __forceinline__ bool empty() const { return top == base; }
     __device__ __forceinline__ void push(uint32_t v) { *top = v; top += BLOCK; }
     __device__ __forceinline__ uint32_t pop() { top -= BLOCK; return *top; }
-    // push(a) if `any`, then push(b) if `both` (both implies any)
-    __device__ __forceinline__ void push2(uint32_t a, bool any, uint32_t b, bool both) {
-        if (any) top[0] = a;
-        if (both) top[BLOCK] = b;
-        top += (any ? BLOCK : 0) + (both ? BLOCK : 0);
-    }
 };
 
 // PairNodes staged in LDS.
@@ -207,22 +201,27 @@ static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const Outp
 // while the bulk of the frame is done in far less; rendered alone, the frame lasts as long as
 // those tiles.  Frames are independent, so a batch puts the long tiles of ALL its frames at the
 // front of one grid (rows are scanned from first_row, the top of the big meshes' screen area,
-// and wrap around) and the cheap tiles of all frames fill the machine behind them.  Wave w
-// renders tile w / n_frames of frame w % n_frames.  The per-frame constants come from an array
+// and wrap around) and the cheap tiles of all frames fill the machine behind them.  The grid
+// takes `chunk` consecutive tiles of frame 0, the same tiles of frame 1, ... and then moves on to
+// the next chunk, so that the waves resident on a CU at any time belong to few frames (their
+// per-frame constants share the scalar cache).  The per-frame constants come from an array
 // in device memory; the frame index is uniform per wave, so they are read with scalar loads.
 // ------------------------------------------------------------------------------------------
 template <int BLOCK, int DEPTH, uint32_t LB>
 __global__ void __launch_bounds__(BLOCK) render_batch(const FrameArgs* __restrict__ frames, const int n_frames, const SceneArgs S,
                                                       uint8_t* __restrict__ rgb_base, const unsigned long long frame_stride,
-                                                      const int first_row) {
+                                                      const int first_row, const int chunk) {
     __shared__ uint32_t lds_stack[DEPTH * BLOCK];
     LdsStack<BLOCK> stack;
     stack.init(&lds_stack[threadIdx.x]);
     GlobalNodes nodes; nodes.all = S.pairs;
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)));
-    const int slot = wave / n_frames;
-    const int f = wave - slot * n_frames;
+    // `chunk` consecutive tiles of one frame, then the same tiles of the next frame, ...
+    const int group = wave / (chunk * n_frames);
+    const int within = wave - group * (chunk * n_frames);
+    const int f = within / chunk;
+    const int slot = group * chunk + (within - f * chunk);
     const FrameArgs& A = frames[f];
     const int tiles_x = (A.width + 7) >> 3, tiles_y = (A.height + 7) >> 3;
     if (slot >= tiles_x * tiles_y) return;
@@ -242,28 +241,29 @@ __global__ void __launch_bounds__(BLOCK) render_batch(const FrameArgs* __restric
 
 template <int BLOCK, int DEPTH>
 static hipError_t launch_batch_t(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb,
-                                 size_t frame_stride, int first_row, hipStream_t stream) {
+                                 size_t frame_stride, int first_row, int chunk, hipStream_t stream) {
     const long long tiles = (long long)((width + 7) / 8) * ((height + 7) / 8);
-    const long long waves = tiles * n_frames;
+    const long long waves = (tiles + chunk - 1) / chunk * chunk * n_frames;
     const int waves_per_block = BLOCK / 64;
     const long long blocks = (waves + waves_per_block - 1) / waves_per_block;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((render_batch<BLOCK, DEPTH, kLeafBatch>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, d_frames, n_frames, S, rgb,
-                       (unsigned long long)frame_stride, first_row);
+                       (unsigned long long)frame_stride, first_row, chunk);
     return hipGetLastError();
 }
 
 hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb, size_t frame_stride,
-                        int first_row, int block, hipStream_t stream) {
+                        int first_row, int chunk, int block, hipStream_t stream) {
     if (n_frames <= 0 || width <= 0 || height <= 0 || !d_frames || !rgb) return hipErrorInvalidValue;
     const int tiles_y = (height + 7) / 8;
     if (first_row < 0 || first_row >= tiles_y) first_row = 0;
+    if (chunk < 1) chunk = 1;
     if (S.stack_entries <= 16) {
-        if (block == 64) return launch_batch_t<64, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, stream);
-        return launch_batch_t<256, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, stream);
+        if (block == 64) return launch_batch_t<64, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, stream);
+        return launch_batch_t<256, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, stream);
     }
-    if (block == 64) return launch_batch_t<64, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, stream);
-    return launch_batch_t<256, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, stream);
+    if (block == 64) return launch_batch_t<64, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, stream);
+    return launch_batch_t<256, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -179,8 +179,47 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
     Query q;
     if (!begin_query<ANY, COUNT, FULL>(M, o, inv, bound, q, work)) return false;
     stack.clear();
-    stack.push(M.root_ref);
     const SlabRay sr = slab_ray(o, inv);
+    if (!FULL) {
+        // Descend through PairNodes without touching the stack for the nearer child; only the
+        // farther child is parked.  The inner loop holds nothing but box tests, the outer step
+        // nothing but triangle tests, so the lanes of a wave do not drag each other through both
+        // kinds of work on every step.
+        uint32_t ref = M.root_ref;
+        bool live = true;
+        while (live) {
+            while (live && !(ref & kLeafBit)) {
+                if (BUDGET && --steps < 0) return false;
+                const PairNode N = nodes(M, ref);
+                if (COUNT) work.slabs += 2;
+                float tl, tr;
+                bool hl, hr;
+                slab_pair(sr, N, tl, tr, hl, hr);
+                if (CULL) { hl = hl && !(tl > q.limit); hr = hr && !(tr > q.limit); }
+                const bool left_first = !(tr < tl);
+                if (hl && hr) {
+                    stack.push(left_first ? N.rref : N.lref);
+                    ref = left_first ? N.lref : N.rref;
+                } else if (hl || hr) {
+                    ref = hl ? N.lref : N.rref;
+                } else if (stack.empty()) {
+                    live = false;
+                } else {
+                    ref = stack.pop();
+                }
+            }
+            if (live) {
+                if (BUDGET && --steps < 0) return false;
+                if (test_leaf<ANY, COUNT, FULL, LB>(M, nodes, ref, o, d, q, work)) return true;
+                if (stack.empty()) live = false;
+                else ref = stack.pop();
+            }
+        }
+        hit = q.hit;
+        return q.found;
+    }
+    // Reference order: every box whose ancestors' boxes pass, no culling.
+    stack.push(M.root_ref);
     while (!stack.empty()) {
         if (BUDGET && --steps < 0) return false;
         const uint32_t ref = stack.pop();
@@ -192,17 +231,9 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
             float tl, tr;
             bool hl, hr;
             slab_pair(sr, N, tl, tr, hl, hr);
-            if (CULL) {
-                hl = hl && !(tl > q.limit);
-                hr = hr && !(tr > q.limit);
-                // Nearer child on top: with both children pending the farther one goes in first.
-                const bool left_first = !(tr < tl);
-                const bool first_is_right = hr && (!hl || left_first);
-                stack.push2(first_is_right ? N.rref : N.lref, hl || hr, left_first ? N.lref : N.rref, hl && hr);
-            } else {
-                if (hr) stack.push(N.rref);
-                if (hl) stack.push(N.lref);
-            }
+            // the reference goes left first (bvh.c:113-124): left child on top
+            if (hr) stack.push(N.rref);
+            if (hl) stack.push(N.lref);
         }
     }
     hit = q.hit;
@@ -315,7 +346,7 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     bool dark = false;
     for (int m = 0; m < A.n_mesh && !dark; m++) {
         const MeshArgs& S = A.mesh[m];
-        const F3 lo = xform_point(S.inv, S.wrow, so);                  // ray.c:19
+        const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);   // ray.c:19
         dark = party.template any<COUNT, FULL>(S, nodes, lo, f3(S.lit_d), f3(S.lit_inv), stack, work);
         if (DEFER && party.exhausted()) { out.deferred = 1; return out; }
     }

@@ -23,7 +23,6 @@ struct ArrayStack {
     bool empty() const { return sp == 0; }
     void push(uint32_t v) { data[sp++] = v; if (sp > high) high = sp; }
     uint32_t pop() { return data[--sp]; }
-    void push2(uint32_t a, bool any, uint32_t b, bool both) { if (any) push(a); if (both) push(b); }
 };
 
 struct EmulMesh {
