@@ -52,6 +52,10 @@ def parse():
     p.add_argument("--batch", type=int, default=8, help="frames per launch (and per gather message for N > 1)")
     p.add_argument("--block", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--verbose", action="store_true", help="phase markers on stderr")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    p.add_argument("--one-device", action="store_true",
+                   help="rehearsal on a one-GPU machine: every rank uses GPU 0 (use with --backend gloo)")
     p.add_argument("--cpu-frames", type=int, default=8)
     return p.parse_args()
 
@@ -95,13 +99,23 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the rendering core has no CPU path")
+    if a.one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
+
+    def say(msg):
+        if a.verbose:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     from raytracer_amd import demo, sharding
     scene = demo.DemoScene(local)
+    say("scene loaded")
     ctx = scene.ctx
     if a.block:
         ctx.set_option("block", a.block)
@@ -131,10 +145,12 @@ def main():
         stream.synchronize()
         own[f] = ctx.last_counters()                        # the traversal the timed kernel runs (ordered, culled)
     ctx.set_option("timing", 0)
+    say("work counted")
 
     # ---- warm-up
     nb = (a.steps + a.batch - 1) // a.batch
-    bufs = [torch.empty((a.batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(nb)]
+    RING = 4                                                   # batches in flight: send buffers and gathers
+    bufs = [torch.empty((a.batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(min(nb, RING))]
     for i in range(0, a.warmup, a.batch):
         fr = seq[i:min(i + a.batch, a.warmup)]
         scene.render_frames(fr, W, H, bufs[0], stream=sptr)
@@ -143,11 +159,13 @@ def main():
         g.submit(bufs[0])
         g.finish()
     torch.cuda.synchronize(dev)
+    say("warm-up rendered and gathered")
     if world > 1:
         dist.barrier()
 
     # ---- timed region: exactly `steps` frames
-    gather = sharding.FrameGather(rank, world) if world > 1 else None
+    # rank 0 drops the gathered frames (an encoder would consume them here)
+    gather = sharding.FrameGather(rank, world, ring=RING - 1) if world > 1 else None
     if gather is not None:
         gather.prealloc(nb, bufs[0])
         dist.barrier()
@@ -155,15 +173,16 @@ def main():
     t0 = time.perf_counter()
     for b in range(nb):
         fr = seq[a.warmup + b * a.batch:a.warmup + min((b + 1) * a.batch, a.steps)]
-        scene.render_frames(fr, W, H, bufs[b], stream=sptr)
+        scene.render_frames(fr, W, H, bufs[b % len(bufs)], stream=sptr)
         if gather is not None:
-            gather.submit(bufs[b])
+            gather.submit(bufs[b % len(bufs)])
     if gather is not None:
         gather.finish()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    say(f"timed region done in {dt:.4f} s")
 
     rays_rank = sum(info[f]["primary_rays"] + info[f]["shadow_rays"] for f in seq[a.warmup:])
     stats = torch.tensor([dt, float(rays_rank)], dtype=torch.float64, device=dev)

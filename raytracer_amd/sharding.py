@@ -32,32 +32,66 @@ class FrameGather:
     Every rank calls submit() the same number of times with a [B, H, W, 3] uint8 tensor (the same
     shape on every rank); rank 0 receives all ranks' batches.  finish() waits for the transfers and,
     on rank 0, returns for each submit call the list of per-rank tensors.
+
+    With `ring` set, at most that many gathers are kept in flight: submit() first waits for the
+    oldest one, hands its frames to `consume` (rank 0; default: drop them) and reuses its receive
+    buffers.  A caller that renders into a ring of `ring` send buffers may therefore overwrite a
+    buffer as soon as the submit() that follows it in the ring has returned.
     """
 
-    def __init__(self, rank: int, world: int, group=None):
+    def __init__(self, rank: int, world: int, group=None, ring: Optional[int] = None,
+                 consume: Optional[Callable[[int, List[torch.Tensor]], None]] = None):
         self.rank, self.world, self.group = rank, world, group
-        self._pending = []      # (work, recv_list or None)
-        self._pool = []         # receive lists allocated ahead of time (rank 0)
+        self.ring, self.consume = ring, consume
+        self._pending = []      # (sequence number, work, recv_list or None)
+        self._pool = []         # receive lists ready for reuse (rank 0)
+        self._seq = 0
 
     def prealloc(self, n_submits: int, like: torch.Tensor):
-        """Allocates rank 0's receive buffers for the next n_submits calls up front, so that no
-        device allocation happens between submit() calls."""
+        """Allocates rank 0's receive buffers for the next n_submits calls (or for the whole ring) up
+        front, so that no device allocation happens between submit() calls."""
         if self.rank == 0 and self.world > 1:
-            self._pool = [[torch.empty_like(like) for _ in range(self.world)] for _ in range(n_submits)]
+            n = min(n_submits, self.ring) if self.ring else n_submits
+            self._pool = [[torch.empty_like(like) for _ in range(self.world)] for _ in range(n)]
+
+    def _retire_oldest(self):
+        seq, work, recv = self._pending.pop(0)
+        if work is not None:
+            work.wait()
+        if self.rank == 0 and recv is not None:
+            if self.consume is not None:
+                self.consume(seq, recv)
+            if self.world > 1:
+                self._pool.append(recv)
 
     def submit(self, batch: torch.Tensor):
+        if self.ring and len(self._pending) >= self.ring:
+            self._retire_oldest()
+        seq = self._seq
+        self._seq += 1
         if self.world == 1:
-            self._pending.append((None, [batch]))
+            self._pending.append((seq, None, [batch]))
             return
+        if batch.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo has no gather for device tensors: go through host memory (rehearsals of the
+            # multi-rank flow on machines without RCCL peers; the GPU path proper is the branch below)
+            batch = batch.cpu()
+            self._pool = [p for p in self._pool if not p[0].is_cuda]
         recv = None
         if self.rank == 0:
             recv = self._pool.pop() if self._pool else [torch.empty_like(batch) for _ in range(self.world)]
         work = dist.gather(batch, gather_list=recv, dst=0, group=self.group, async_op=True)
-        self._pending.append((work, recv))
+        self._pending.append((seq, work, recv))
 
     def finish(self) -> Optional[List[List[torch.Tensor]]]:
+        """Waits for everything in flight.  Without a ring: returns rank 0's received batches in submit
+        order.  With a ring: the remaining batches go to `consume` and nothing is returned."""
+        if self.ring:
+            while self._pending:
+                self._retire_oldest()
+            return None
         out = []
-        for work, recv in self._pending:
+        for _, work, recv in self._pending:
             if work is not None:
                 work.wait()
             out.append(recv)

@@ -128,6 +128,50 @@ def test_frame_gather_keeps_submit_order_with_several_in_flight(tmp_path):
     assert os.path.exists(os.path.join(tmp_path, "ok"))
 
 
+def _ring_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.sharding import FrameGather
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = []
+
+    def consume(seq, per_rank):
+        seen.append((seq, [int(t.flatten()[0]) for t in per_rank]))
+
+    g = FrameGather(rank, world, ring=2, consume=consume)
+    like = torch.zeros((2, 3, 4, 3), dtype=torch.uint8)
+    g.prealloc(7, like)
+    send = [torch.zeros_like(like) for _ in range(3)]            # ring of send buffers, one more than gathers in flight
+    for i in range(7):
+        send[i % 3].fill_(10 * rank + i)
+        g.submit(send[i % 3])
+        assert len(g._pending) <= 2
+    assert g.finish() is None
+    if rank == 0:
+        assert seen == [(i, [10 * r + i for r in range(world)]) for i in range(7)], seen
+        assert len(g._pool) == 2                                 # receive buffers were recycled, not re-allocated
+        open(os.path.join(out_dir, "ring_ok"), "w").write("ok")
+    else:
+        assert seen == []
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_gather_ring_bounds_what_is_in_flight(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert os.path.exists(os.path.join(tmp_path, "ring_ok"))
+
+
 def test_frame_gather_single_rank_is_a_passthrough():
     import torch
     from raytracer_amd.sharding import FrameGather
