@@ -36,6 +36,8 @@ typedef enum {
 #define RT_MAX_TREE_DEPTH    30         /* deepest BVH the traversal stack covers */
 #define RT_MAX_MESH_TRIS     (1 << 24)  /* triangles per mesh */
 #define RT_MAX_BATCH         16         /* frames per rt_render_frames call */
+#define RT_MAX_LIGHTS        4          /* lights per rt_render_frame_sampled call */
+#define RT_MAX_SAMPLES       64         /* camera rays per pixel in rt_render_frame_sampled */
 
 /* ---- reference-layout structs ---------------------------------------------------------- */
 typedef struct { float x, y, z; } rt_vec3;                       /* math/vec3.h:6 */
@@ -135,6 +137,22 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
 int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
                      const rt_transform* transforms, int32_t n_frames, int32_t n_transforms,
                      int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream);
+
+/* Beyond the reference (it has one ray through the pixel centre, scene.c:61-62, and one light, scene.h:17):
+ * samples_per_pixel jittered camera rays per pixel and n_lights directional lights, every per-ray
+ * operation as in render_scene.  Sample s of pixel (x,y) goes through (x+jx, y+jy) with (jx,jy) = (0.5,0.5)
+ * when samples_per_pixel is 1 and otherwise two 24-bit fractions from a hash of (x, y, s, seed); every
+ * light gets its own shadow ray and contributes (texel*color)*d, d = 0.2 or max(0.2, n.L) when
+ * unblocked; a sample's value is min(colour*255, 255) (50 for a miss); the pixel is the mean of its
+ * samples' values cast to unsigned char.  With one sample and one light the result equals
+ * rt_render_frame's.  lights[i].direction must be normalised (create_directional_light does it).
+ * d_hit_id (optional) receives the id hit by sample 0.  With RT_FLAG_COUNT_WORK, rt_last_counters
+ * reports primary_rays = pixels*samples, shadow_rays = hit samples*lights, hit_pixels = hit samples,
+ * shadowed_pixels = blocked (sample, light) pairs.  RT_FLAG_REFERENCE_ORDER is not supported here. */
+int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light* lights, int32_t n_lights,
+                            const rt_transform* transforms, int32_t n_transforms,
+                            int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed,
+                            uint32_t flags, void* d_rgb, void* d_hit_id, void* stream);
 
 /* Same, for callers that hold host buffers (what scene->frames[current_frame] is in the
  * reference): renders into context-owned device planes, waits, and copies back. */

@@ -128,6 +128,11 @@ def lib():
         L.orc_render_frame.restype = None
         L.orc_render_frame.argtypes = [C.POINTER(Mesh), C.c_int32, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int32]
+        L.orc_sample_offset.restype = None
+        L.orc_sample_offset.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_render_frame_sampled.restype = None
+        L.orc_render_frame_sampled.argtypes = [C.POINTER(Mesh), C.c_int32, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.c_int32,
+                                               C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int32]
         L.orc_animation_transforms.restype = None
         L.orc_animation_transforms.argtypes = [C.c_int32, C.POINTER(Transform)]
         L.orc_max_threads.restype = C.c_int
@@ -296,6 +301,19 @@ def render_frame(meshes: Sequence[HostMesh], transforms: Sequence[Transform], ca
                            _ptr(hid) if debug else None, _ptr(ht) if debug else None, _ptr(sh) if debug else None,
                            C.byref(cnt), threads)
     return Frame(rgb, hid, ht, sh, cnt.as_dict())
+
+
+def render_frame_sampled(meshes: Sequence[HostMesh], transforms: Sequence[Transform], cam: Camera, lights: Sequence[Light],
+                         spp: int, seed: int, width: int, height: int, threads: int = 0) -> Frame:
+    """Several camera rays per pixel, several lights (rt_render_frame_sampled's definition).  hit_id is sample 0's."""
+    arr = (Mesh * len(meshes))(*[m.as_struct(tf) for m, tf in zip(meshes, transforms)])
+    larr = (Light * len(lights))(*lights)
+    rgb = np.zeros((height, width, 3), np.uint8)
+    hid = np.zeros((height, width), np.int32)
+    cnt = Counters()
+    lib().orc_render_frame_sampled(arr, len(meshes), C.byref(cam), larr, len(lights), spp, seed, width, height,
+                                   _ptr(rgb), _ptr(hid), C.byref(cnt), threads)
+    return Frame(rgb, hid, None, None, cnt.as_dict())
 
 
 def scaled_size(width: int, height: int, scale_factor: float):

@@ -467,6 +467,110 @@ void orc_render_frame(const OMesh* meshes, int32_t mesh_count, const OCamera* ca
     }
 }
 
+/* ------------------------------------------------------------------ sampled frames (beyond the reference)
+ * Several camera rays per pixel and several lights around the reference's per-ray operations.  There is no
+ * reference for this: it is pinned only where it coincides with the reference (spp == 1, one light),
+ * where it must equal orc_render_frame.  Definition: include/rt_mi355.h, rt_render_frame_sampled. */
+static uint32_t mix32(uint32_t v) {
+    v = v * 747796405u + 2891336453u;
+    uint32_t w = ((v >> ((v >> 28) + 4u)) ^ v) * 277803737u;
+    return (w >> 22) ^ w;
+}
+
+void orc_sample_offset(uint32_t x, uint32_t y, uint32_t s, uint32_t seed, float* jx, float* jy) {
+    uint32_t h0 = mix32(x ^ mix32(y ^ mix32(s ^ mix32(seed))));
+    uint32_t h1 = mix32(h0);
+    *jx = (float)(h0 >> 8) * (1.0f / 16777216.0f);
+    *jy = (float)(h1 >> 8) * (1.0f / 16777216.0f);
+}
+
+void orc_render_frame_sampled(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* lights,
+                              int32_t n_lights, int32_t spp, uint32_t seed, int32_t width, int32_t height,
+                              uint8_t* rgb, int32_t* hit_id, OCounters* counters, int32_t threads) {
+    float aspect = (float)width / height;
+    uint64_t c_prim = 0, c_shad = 0, c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#endif
+    #pragma omp parallel for schedule(dynamic, 4) num_threads(threads) \
+        reduction(+ : c_prim, c_shad, c_slab, c_tri, c_hit, c_dark)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            Work w = {0, 0};
+            float acc[3] = {0, 0, 0};
+            int first_id = -1;
+            for (int s = 0; s < spp; s++) {
+                float jx = 0.5f, jy = 0.5f;
+                if (spp > 1) orc_sample_offset((uint32_t)x, (uint32_t)y, (uint32_t)s, seed, &jx, &jy);
+                ORay ray = orc_camera_ray(cam, (x + jx) / width, (y + jy) / height, aspect);
+                c_prim++;
+                float closest = 1e30f;
+                int hit = 0, hit_mesh = -1, hit_tri = -1;
+                OVec2 uv = {0, 0};
+                OVec3 normal = {0, 0, 0};
+                for (int m = 0; m < mesh_count; m++) {
+                    const OMesh* mesh = &meshes[m];
+                    float t = closest, u = 0, v = 0;
+                    int32_t ti = 0;
+                    ORay local = orc_transform_ray(ray, mesh->transform);
+                    if (walk(mesh->nodes, 0, local, mesh->triangles, &t, &u, &v, &ti, &w) && t < closest) {
+                        closest = t; hit = 1; hit_mesh = m; hit_tri = ti;
+                        const OTriangle* tr = &mesh->triangles[ti];
+                        float bw = 1.0f - u - v;
+                        uv.u = bw * tr->t0.u + u * tr->t1.u + v * tr->t2.u;
+                        uv.v = bw * tr->t0.v + u * tr->t1.v + v * tr->t2.v;
+                        normal = v_unit(v_add(v_add(v_scale(tr->n0, bw), v_scale(tr->n1, u)), v_scale(tr->n2, v)));
+                        normal = orc_transform_normal(normal, mesh->transform);
+                    }
+                }
+                float value[3] = {50.0f, 50.0f, 50.0f};
+                if (hit) {
+                    c_hit++;
+                    if (s == 0) first_id = (hit_mesh << 24) | hit_tri;
+                    float tex[3];
+                    orc_sample_texture(&meshes[hit_mesh], uv.u, uv.v, tex);
+                    OVec3 p = v_add(ray.origin, v_scale(ray.direction, closest));
+                    ORay sray;
+                    sray.origin = v_add(p, v_scale(normal, 0.001f));
+                    OVec3 color = {0, 0, 0};
+                    for (int l = 0; l < n_lights; l++) {
+                        sray.direction = lights[l].direction;
+                        c_shad++;
+                        int dark = 0;
+                        for (int m = 0; m < mesh_count && !dark; m++) {
+                            float st = 1e30f, su = 0, sv = 0;
+                            int32_t si = 0;
+                            ORay local = orc_transform_ray(sray, meshes[m].transform);
+                            if (walk(meshes[m].nodes, 0, local, meshes[m].triangles, &st, &su, &sv, &si, &w)) dark = 1;
+                        }
+                        float diffuse = 0.2f;
+                        if (!dark) diffuse = fmaxf(diffuse, v_dot(normal, lights[l].direction));
+                        else c_dark++;
+                        OVec3 term = v_scale(v_mul(v3(tex[0], tex[1], tex[2]), lights[l].color), diffuse);
+                        color = l == 0 ? term : v_add(color, term);
+                    }
+                    value[0] = fminf(color.x * 255.0f, 255.0f);
+                    value[1] = fminf(color.y * 255.0f, 255.0f);
+                    value[2] = fminf(color.z * 255.0f, 255.0f);
+                }
+                for (int k = 0; k < 3; k++) acc[k] = s == 0 ? value[k] : acc[k] + value[k];
+            }
+            size_t px = (size_t)y * width + x;
+            for (int k = 0; k < 3; k++) {
+                float v = spp > 1 ? acc[k] / (float)spp : acc[k];
+                rgb[px * 3 + k] = (unsigned char)v;
+            }
+            if (hit_id) hit_id[px] = first_id;
+            c_slab += w.slabs; c_tri += w.tris;
+        }
+    }
+    if (counters) {
+        counters->primary_rays = c_prim; counters->shadow_rays = c_shad;
+        counters->slab_tests = c_slab; counters->tri_tests = c_tri;
+        counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
+    }
+}
+
 /* ------------------------------------------------------------------ driver animation (raytracer.c:41-53) */
 void orc_animation_transforms(int32_t frame, OTransform out[3]) {
     /* raytracer.c:41: the factor 2.0f*M_PI/120.0f is a double; the product is narrowed to float. */

@@ -108,6 +108,11 @@ void   orc_render_frame(const OMesh* meshes, int32_t mesh_count, const OCamera* 
  * (mesh 0) and the treasure (mesh 1) at a frame; the ground keeps the identity. */
 void   orc_animation_transforms(int32_t frame, OTransform out[3]);
 
+/* Sampled frames: several camera rays per pixel, several lights (no counterpart in the reference). */
+void   orc_sample_offset(uint32_t x, uint32_t y, uint32_t s, uint32_t seed, float* jx, float* jy);
+void   orc_render_frame_sampled(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* lights,
+                                int32_t n_lights, int32_t spp, uint32_t seed, int32_t width, int32_t height,
+                                uint8_t* rgb, int32_t* hit_id, OCounters* counters, int32_t threads);
 int    orc_max_threads(void);
 
 #ifdef __cplusplus

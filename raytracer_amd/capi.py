@@ -21,6 +21,8 @@ RT_FLAG_COUNT_WORK = 0x1
 RT_FLAG_REFERENCE_ORDER = 0x2
 RT_MAX_MESHES = 8
 RT_MAX_BATCH = 16
+RT_MAX_LIGHTS = 4
+RT_MAX_SAMPLES = 64
 
 
 class Vec3(C.Structure):
@@ -56,6 +58,7 @@ EXPORTS = [
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
+    "rt_render_frame_sampled",
 ]
 
 _lib = None
@@ -104,6 +107,8 @@ def lib():
                                            vp, vp, vp, vp]
         L.rt_render_frames.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, i32,
                                        vp, C.c_size_t, vp]
+        L.rt_render_frame_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, i32, i32,
+                                              u32, u32, vp, vp, vp]
         L.rt_scaled_size.argtypes = [i32, i32, C.c_float, C.POINTER(i32), C.POINTER(i32)]
         L.rt_upscale_frames.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
         L.rt_upscale_frame_host.argtypes = [vp, vp, i32, i32, i32, i32, vp]
@@ -253,6 +258,15 @@ class Context:
                                                hid.ctypes.data if debug else None, ht.ctypes.data if debug else None,
                                                sh.ctypes.data if debug else None))
         return rgb, hid, ht, sh
+
+    def render_sampled(self, camera: Camera, lights: Sequence[Light], transforms: Sequence[Transform], width: int, height: int,
+                       samples_per_pixel: int, seed: int, rgb, hit_id=None, flags: int = 0, stream: Optional[int] = None):
+        """rt_render_frame_sampled into device buffers (asynchronous)."""
+        arr = (Transform * max(len(transforms), 1))(*transforms)
+        larr = (Light * max(len(lights), 1))(*lights)
+        self._check(lib().rt_render_frame_sampled(self._h, C.byref(camera), larr, len(lights), arr, len(transforms), int(width),
+                                                  int(height), int(samples_per_pixel), int(seed) & 0xFFFFFFFF, int(flags),
+                                                  _dev_ptr(rgb), _dev_ptr(hit_id), stream))
 
     def upscale_frames(self, rgb, n_frames: int, width: int, height: int, scaled_width: int, scaled_height: int, argb,
                        frame_stride: Optional[int] = None, out_stride: Optional[int] = None, stream: Optional[int] = None):

@@ -494,6 +494,40 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light
     return RT_OK;
 }
 
+int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light* lights, int32_t n_lights, const rt_transform* transforms,
+                            int32_t n_transforms, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed, uint32_t flags,
+                            void* d_rgb, void* d_hit_id, void* stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!camera || !lights || !d_rgb) return fail(ctx, RT_ERR_INVALID, "camera, lights and d_rgb are required");
+    if (n_lights < 1 || n_lights > RT_MAX_LIGHTS) return fail(ctx, RT_ERR_UNSUPPORTED, "n_lights must be 1..RT_MAX_LIGHTS");
+    if (samples_per_pixel < 1 || samples_per_pixel > RT_MAX_SAMPLES) return fail(ctx, RT_ERR_UNSUPPORTED, "samples_per_pixel must be 1..RT_MAX_SAMPLES");
+    if (flags & RT_FLAG_REFERENCE_ORDER) return fail(ctx, RT_ERR_UNSUPPORTED, "RT_FLAG_REFERENCE_ORDER is not available for sampled frames");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    if (n_transforms != (int32_t)ctx->meshes.size() || (n_transforms > 0 && !transforms))
+        return fail(ctx, RT_ERR_INVALID, "one transform per uploaded mesh is required");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int cst = commit_scene(ctx);
+    if (cst != RT_OK) return cst;
+    const SceneArgs S = scene_args(ctx);
+    FrameArgs A;
+    fill_frame(ctx, *camera, lights[0], transforms, n_transforms, width, height, flags, A);
+    SampleArgs X;
+    fill_samples(lights, n_lights, samples_per_pixel, seed, A, X);
+    OutputPlanes O;
+    O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_id; O.hit_t = nullptr; O.shadow = nullptr;
+    O.counters = ctx->d_counters; O.tile_clock = nullptr;
+    if (flags & RT_FLAG_COUNT_WORK) {
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DeviceCounters), s));
+        ctx->counters_pending = true;
+    }
+    if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
+    hipError_t le = launch_sampled(A, X, S, O, ctx->cfg.block, s);
+    if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
+    if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
+    return RT_OK;
+}
+
 int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
                          int32_t n_transforms, int32_t width, int32_t height, uint32_t flags, uint8_t* h_rgb,
                          int32_t* h_hit_id, float* h_hit_t, uint8_t* h_shadow) {

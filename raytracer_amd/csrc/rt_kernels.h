@@ -40,6 +40,10 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
 hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb, size_t frame_stride,
                         int first_row, int chunk, int block, hipStream_t stream);
 
+// Enqueues one sampled frame (X.spp camera rays per pixel, X.n_lights lights).  O.rgb is required,
+// O.hit_id optional (sample 0), the other planes are not written.  block: 64 or 256.
+hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneArgs& S, const OutputPlanes& O, int block, hipStream_t stream);
+
 // Enqueues the bicubic upscale of n_frames RGB8 frames (width x height, frame f at rgb + f*frame_stride
 // bytes) to ARGB32 frames (scaled_width x scaled_height, frame f at argb + f*out_stride pixels).
 // scaled sizes must be at least 2 (the source coordinate divides by scaled-1).

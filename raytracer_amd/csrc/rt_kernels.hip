@@ -22,6 +22,7 @@
 
 #include "rt_kernels.h"
 #include "rt_pixel.h"
+#include "rt_sampled.h"
 
 namespace rt {
 
@@ -125,6 +126,62 @@ static hipError_t launch_direct(const FrameArgs& A, const SceneArgs& S, const Ou
     else if (count)     hipLaunchKernelGGL((render_direct<BLOCK, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     else if (full)      hipLaunchKernelGGL((render_direct<BLOCK, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     else                hipLaunchKernelGGL((render_direct<BLOCK, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Sampled frames (rt_sampled.h): several camera rays per pixel, several lights.  One thread per
+// pixel loops over its samples, so the lanes of a wave stay on neighbouring rays throughout.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) render_sampled(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
+    __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
+    LdsStack<BLOCK> stack;
+    stack.init(&lds_stack[threadIdx.x]);
+    GlobalNodes nodes; nodes.all = S.pairs;
+    const int tiles_x = (A.width + 7) >> 3;
+    const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    int px, py;
+    tile_pixel(tile, threadIdx.x & 63, tiles_x, px, py);
+    LaneTotals tot = {0, 0, 0, 0, 0};
+    if (px < A.width && py < A.height) {
+        Work work; work.slabs = 0; work.tris = 0;
+        const SampledOut r = shade_sampled_pixel<COUNT>(A, X, nodes, Solo(), px, py, stack, work);
+        const size_t p = (size_t)py * (size_t)A.width + (size_t)px;
+        uint8_t* rgb = O.rgb + p * 3;
+        rgb[0] = r.r; rgb[1] = r.g; rgb[2] = r.b;
+        if (O.hit_id) O.hit_id[p] = r.hit_id;
+        tot.pixels = (unsigned long long)X.spp; tot.hits = r.hits; tot.darks = r.darks; tot.slabs = work.slabs; tot.tris = work.tris;
+    }
+    if (COUNT) {
+        // shadow rays = hit samples x lights
+        const unsigned long long prim = wave_sum(tot.pixels), hit = wave_sum(tot.hits), dark = wave_sum(tot.darks);
+        const unsigned long long slabs = wave_sum(tot.slabs), tris = wave_sum(tot.tris);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&O.counters->primary_rays, prim);
+            atomicAdd(&O.counters->shadow_rays, hit * (unsigned long long)X.n_lights);
+            atomicAdd(&O.counters->hit_pixels, hit);
+            atomicAdd(&O.counters->shadowed_pixels, dark);
+            atomicAdd(&O.counters->slab_tests, slabs);
+            atomicAdd(&O.counters->tri_tests, tris);
+        }
+    }
+}
+
+hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneArgs& S, const OutputPlanes& O, int block, hipStream_t stream) {
+    if (A.width <= 0 || A.height <= 0 || X.spp < 1 || X.spp > kMaxSamples || X.n_lights < 1 || X.n_lights > kMaxLights || !O.rgb)
+        return hipErrorInvalidValue;
+    const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
+    if (count && !O.counters) return hipErrorInvalidValue;
+    const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
+    if (block == 256) {
+        const int blocks = (tiles + 3) / 4;
+        if (count) hipLaunchKernelGGL((render_sampled<256, true>), dim3(blocks), dim3(256), 0, stream, A, X, S, O);
+        else       hipLaunchKernelGGL((render_sampled<256, false>), dim3(blocks), dim3(256), 0, stream, A, X, S, O);
+    } else {
+        if (count) hipLaunchKernelGGL((render_sampled<64, true>), dim3(tiles), dim3(64), 0, stream, A, X, S, O);
+        else       hipLaunchKernelGGL((render_sampled<64, false>), dim3(tiles), dim3(64), 0, stream, A, X, S, O);
+    }
     return hipGetLastError();
 }
 

@@ -106,6 +106,20 @@ struct FrameArgs {
     MeshArgs mesh[kMaxMeshes];
 };
 
+// Sampled rendering (several jittered camera rays per pixel, several directional lights): what it
+// needs beyond FrameArgs.  Light 0 of a sampled frame is also the light in FrameArgs.
+constexpr int kMaxLights = 4;
+constexpr int kMaxSamples = 64;
+struct SampleArgs {
+    int32_t spp;                 // camera rays per pixel; 1 = the pixel centre
+    uint32_t seed;
+    int32_t n_lights;
+    int32_t pad;
+    float light_dir[kMaxLights][3], light_color[kMaxLights][3];
+    float lit_d[kMaxMeshes][kMaxLights][3];      // light direction in mesh space, normalised
+    float lit_inv[kMaxMeshes][kMaxLights][3];    // its reciprocal
+};
+
 struct DeviceCounters {          // accumulated with atomics when counting is requested
     unsigned long long primary_rays, shadow_rays, slab_tests, tri_tests, hit_pixels, shadowed_pixels;
 };

@@ -261,6 +261,25 @@ inline void fill_placement(const rt_transform& tf, const FrameArgs& A, MeshArgs&
     if (M.wrow[0] == 0.0f && M.wrow[1] == 0.0f && M.wrow[2] == 0.0f && M.wrow[3] != 0.0f) M.w_mode = (M.wrow[3] == 1.0f) ? 2u : 1u;
 }
 
+// Sampling part of a frame: the lights and, per mesh, their directions in mesh space (ray.c:20,22
+// applied to the shadow ray's direction, which is the light's for every pixel).  Call after every
+// MeshArgs of A has its placement.
+inline void fill_samples(const rt_light* lights, int32_t n_lights, int32_t spp, uint32_t seed, const FrameArgs& A, SampleArgs& X) {
+    memset(&X, 0, sizeof(X));
+    X.spp = spp; X.seed = seed; X.n_lights = n_lights;
+    for (int32_t l = 0; l < n_lights; l++) {
+        const F3 d = f3(lights[l].direction.x, lights[l].direction.y, lights[l].direction.z);
+        X.light_dir[l][0] = d.x; X.light_dir[l][1] = d.y; X.light_dir[l][2] = d.z;
+        X.light_color[l][0] = lights[l].color.x; X.light_color[l][1] = lights[l].color.y; X.light_color[l][2] = lights[l].color.z;
+        for (int32_t m = 0; m < A.n_mesh; m++) {
+            const F3 ld = unit(xform_vector<4>(A.mesh[m].inv, d));
+            const F3 li = recip(ld);
+            X.lit_d[m][l][0] = ld.x; X.lit_d[m][l][1] = ld.y; X.lit_d[m][l][2] = ld.z;
+            X.lit_inv[m][l][0] = li.x; X.lit_inv[m][l][1] = li.y; X.lit_inv[m][l][2] = li.z;
+        }
+    }
+}
+
 // ---- work layout helpers (never used for results) -------------------------------------------
 struct WorldBox { double lo[3], hi[3]; double corner[8][3]; };
 

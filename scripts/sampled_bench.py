@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Times the stress configuration: 3840x2160, 16 jittered camera rays per pixel, several lights
+(rt_render_frame_sampled), frames resident in HBM.  Prints one JSON line.
+
+    python scripts/sampled_bench.py --spp 16 --lights 2 --frames 0,45
+"""
+import argparse
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--width", type=int, default=3840)
+    p.add_argument("--height", type=int, default=2160)
+    p.add_argument("--spp", type=int, default=16)
+    p.add_argument("--lights", type=int, default=2)
+    p.add_argument("--frames", default="0,45")
+    p.add_argument("--reps", type=int, default=3)
+    a = p.parse_args()
+    from raytracer_amd import capi, demo, host_api as H
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    scene = demo.DemoScene(0)
+    ctx = scene.ctx
+    L = H.lib()
+    dirs = [(1, 1, -1), (-1, 2, 0.5), (0.2, 1, 0.8), (-0.5, 0.7, -1)]
+    cols = [(1.4, 1.4, 1.4), (0.3, 0.5, 0.9), (0.5, 0.2, 0.2), (0.2, 0.4, 0.2)]
+    lights = []
+    for d, c in list(zip(dirs, cols))[:a.lights]:
+        l = L.create_directional_light(H.Vec3(*d), H.Vec3(*c))
+        lights.append(capi.Light(capi.Vec3(l.direction.x, l.direction.y, l.direction.z), capi.Vec3(l.color.x, l.color.y, l.color.z)))
+    W, Hh = a.width, a.height
+    rgb = torch.empty((Hh, W, 3), dtype=torch.uint8, device=dev)
+    rows = []
+    for f in [int(x) for x in a.frames.split(",")]:
+        tfs = scene.transforms(f)
+        ctx.render_sampled(scene.camera, lights, tfs, W, Hh, a.spp, 0, rgb, flags=capi.RT_FLAG_COUNT_WORK)
+        ctx.sync()
+        c = ctx.last_counters()
+        ms = []
+        for _ in range(a.reps):
+            ctx.render_sampled(scene.camera, lights, tfs, W, Hh, a.spp, 0, rgb)
+            ms.append(ctx.last_kernel_ms())
+        t = float(np.median(ms))
+        rays = c["primary_rays"] + c["shadow_rays"]
+        rows.append({"frame": f, "ms": round(t, 3), "primary_rays": c["primary_rays"], "shadow_rays": c["shadow_rays"],
+                     "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1)})
+    out = {"metric": "Mrays/s (primary+shadow), sampled frame", "unit": "Mrays/s",
+           "value": round(float(np.mean([r["Mrays_per_s"] for r in rows])), 1),
+           "config": {"workload": f"{W}x{Hh}, {a.spp} jittered camera rays per pixel, {a.lights} lights, drone/treasure/ground scene"},
+           "dtype": "f32", "frames": rows}
+    print(json.dumps(out), flush=True)
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()

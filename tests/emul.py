@@ -55,6 +55,10 @@ def lib():
                                      C.POINTER(C.c_uint32)]
         L.emul_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32,
                                   vp, vp, vp, vp, C.POINTER(Counters), i32, vp, vp]
+        L.emul_sample_offset.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_float)] * 2
+        L.emul_sample_offset.restype = None
+        L.emul_render_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, C.c_uint32,
+                                          i32, i32, vp, vp, C.POINTER(Counters)]
         L.emul_upscale.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         L.emul_upscale.restype = None
         _lib = L
@@ -121,6 +125,18 @@ class Scene:
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_id": hid, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(), "px_slabs": ps,
                 "px_tris": pt, "stack_high": lib().emul_stack_high(self.h)}
+
+    def render_sampled(self, cam, lights, tfs, spp, seed, w, h):
+        arr = (Transform * max(len(tfs), 1))(*[conv(t, Transform) for t in tfs])
+        larr = (Light * len(lights))(*[conv(l, Light) for l in lights])
+        rgb = np.zeros((h, w, 3), np.uint8)
+        hid = np.zeros((h, w), np.int32)
+        cnt = Counters()
+        cam2 = conv(cam, Camera)
+        st = lib().emul_render_sampled(self.h, C.byref(cam2), larr, len(lights), arr, len(tfs), spp, seed, w, h,
+                                       rgb.ctypes.data, hid.ctypes.data, C.byref(cnt))
+        assert st == 0, self.error()
+        return {"rgb": rgb, "hit_id": hid, "counters": cnt.as_dict()}
 
     def close(self):
         if self.h:

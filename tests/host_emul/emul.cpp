@@ -11,6 +11,7 @@
 #include "../../raytracer_amd/csrc/rt_bicubic.h"
 #include "../../raytracer_amd/csrc/rt_pack.h"
 #include "../../raytracer_amd/csrc/rt_pixel.h"
+#include "../../raytracer_amd/csrc/rt_sampled.h"
 
 using namespace rt;
 
@@ -132,6 +133,50 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
     s->stack_high = high;
     if (counters) {
         counters->primary_rays = (uint64_t)width * height; counters->shadow_rays = c_hit;
+        counters->slab_tests = c_slab; counters->tri_tests = c_tri;
+        counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
+    }
+    return RT_OK;
+}
+
+void emul_sample_offset(uint32_t x, uint32_t y, uint32_t s, uint32_t seed, float* jx, float* jy) { sample_offset(x, y, s, seed, *jx, *jy); }
+
+// The product's sampled pixel (rt_sampled.h) over a frame.
+int emul_render_sampled(void* sp, const rt_camera* cam, const rt_light* lights, int32_t n_lights, const rt_transform* tfs, int32_t n_tf,
+                        int32_t spp, uint32_t seed, int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_id, rt_counters* counters) {
+    EmulScene* s = (EmulScene*)sp;
+    if (n_tf != (int32_t)s->meshes.size() || n_tf > kMaxMeshes || n_lights < 1 || n_lights > kMaxLights) { s->err = "counts"; return RT_ERR_INVALID; }
+    FrameArgs A; memset(&A, 0, sizeof A);
+    fill_camera(*cam, lights[0], width, height, A);
+    A.n_mesh = n_tf;
+    uint32_t base = 0;
+    for (int m = 0; m < n_tf; m++) {
+        MeshArgs& M = A.mesh[m];
+        const EmulMesh& E = s->meshes[(size_t)m];
+        M.pair_base = base; M.pair_count = (uint32_t)E.pk.pairs.size(); base += M.pair_count;
+        M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
+        memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
+        M.root_ref = E.pk.root_ref; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        fill_placement(tfs[m], A, M);
+    }
+    SampleArgs X;
+    fill_samples(lights, n_lights, spp, seed, A, X);
+    GlobalNodes nodes; nodes.all = s->all_pairs.data();
+    unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
+    #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_slab, c_tri, c_hit, c_dark)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            ArrayStack st;
+            Work w; w.slabs = 0; w.tris = 0;
+            const SampledOut r = shade_sampled_pixel<true>(A, X, nodes, Solo(), x, y, st, w);
+            const size_t p = (size_t)y * width + x;
+            rgb[p * 3] = r.r; rgb[p * 3 + 1] = r.g; rgb[p * 3 + 2] = r.b;
+            if (hit_id) hit_id[p] = r.hit_id;
+            c_slab += w.slabs; c_tri += w.tris; c_hit += r.hits; c_dark += r.darks;
+        }
+    }
+    if (counters) {
+        counters->primary_rays = (uint64_t)width * height * (uint64_t)spp; counters->shadow_rays = c_hit * (uint64_t)n_lights;
         counters->slab_tests = c_slab; counters->tri_tests = c_tri;
         counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
     }

@@ -159,9 +159,11 @@ def test_batched_frames_equal_single_frames(capi, ctx, po, golden_hashes, block)
         ctx.set_option("block", block)
         # images back to back, and with a padded stride
         out = torch.zeros((len(frames), h, w, 3), dtype=torch.uint8, device=dev)
-        ctx.render_frames(cam, light, tfs, w, h, out, stream=stream.cuda_stream)
         stride = w * h * 3 + 4096
         padded = torch.full((len(frames) * stride,), 7, dtype=torch.uint8, device=dev)
+        small = torch.zeros((3, 5, 7, 3), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()          # the fills above ran on torch's stream, the launches below use another one
+        ctx.render_frames(cam, light, tfs, w, h, out, stream=stream.cuda_stream)
         ctx.render_frames(cam, light, tfs, w, h, padded, frame_stride=stride, stream=stream.cuda_stream)
         stream.synchronize()
         for i, f in enumerate(frames):
@@ -175,7 +177,6 @@ def test_batched_frames_equal_single_frames(capi, ctx, po, golden_hashes, block)
             assert np.array_equal(chunk[:w * h * 3].reshape(h, w, 3), img)
             assert (chunk[w * h * 3:] == 7).all()                       # padding untouched
         # ragged size, one frame, more frames than slots in flight
-        small = torch.zeros((3, 5, 7, 3), dtype=torch.uint8, device=dev)
         for _ in range(6):
             ctx.render_frames(cam, light, tfs[:3], 7, 5, small, stream=stream.cuda_stream)
         stream.synchronize()

@@ -1,0 +1,171 @@
+"""Sampled frames (several jittered camera rays per pixel, several lights): an extension beyond the
+reference, which has one ray through the pixel centre and one light.  Parity is pinned where the
+extension coincides with the reference -- one sample, one light -- and the product is held to the
+CPU restatement of the definition (include/rt_mi355.h, rt_render_frame_sampled) everywhere else;
+for those cases there is no reference output: parity unpinned by the reference, bit-exact against the
+restatement."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import emul
+
+
+def lights3(po):
+    return [po.default_light(),
+            po.lib().orc_make_light(po.vec3(-1, 2, 0.5), po.vec3(0.3, 0.5, 0.9)),
+            po.lib().orc_make_light(po.vec3(0, 1, 0), po.vec3(0.4, 0.1, 0.1))]
+
+
+@pytest.fixture(scope="module")
+def em_default(meshes):
+    s = emul.Scene()
+    for m in meshes:
+        assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+    yield s
+    s.close()
+
+
+# ------------------------------------------------------------------------------------------ CPU
+
+def test_one_sample_one_light_is_the_reference_frame(po, meshes, golden_frames):
+    for f in (0, 45, 95):
+        fr = po.render_frame_sampled(meshes, po.animation_transforms(f), po.default_camera(), [po.default_light()], 1, 123, 240, 135)
+        assert np.array_equal(fr.rgb, golden_frames[f"f{f}_rgb"])
+        assert np.array_equal(fr.hit_id, golden_frames[f"f{f}_hit_id"])
+
+
+def test_sample_offsets(po):
+    """24-bit fractions in [0,1), a function of (x, y, s, seed) only, same in the oracle and the product."""
+    rng = np.random.default_rng(1)
+    seen = set()
+    for _ in range(2000):
+        x, y, s, seed = (int(v) for v in rng.integers(0, 2**32, 4, dtype=np.uint64))
+        a, b, c, d = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        po.lib().orc_sample_offset(x, y, s, seed, C.byref(a), C.byref(b))
+        emul.lib().emul_sample_offset(x, y, s, seed, C.byref(c), C.byref(d))
+        assert (a.value, b.value) == (c.value, d.value)
+        assert 0.0 <= a.value < 1.0 and 0.0 <= b.value < 1.0
+        assert a.value * 16777216.0 == int(a.value * 16777216.0)
+        seen.add((a.value, b.value))
+    assert len(seen) > 1990
+    # neighbouring samples of one pixel are spread out, not clustered
+    pts = []
+    for s in range(64):
+        a, b = C.c_float(), C.c_float()
+        po.lib().orc_sample_offset(10, 20, s, 0, C.byref(a), C.byref(b))
+        pts.append((a.value, b.value))
+    pts = np.array(pts)
+    assert 0.3 < pts[:, 0].mean() < 0.7 and 0.3 < pts[:, 1].mean() < 0.7
+    assert pts[:, 0].min() < 0.15 and pts[:, 0].max() > 0.85
+
+
+@pytest.mark.parametrize("spp,n_lights", [(1, 1), (4, 1), (1, 3), (5, 2), (16, 4)])
+def test_product_pixel_code_equals_restatement(po, meshes, em_default, spp, n_lights):
+    ls = (lights3(po) + [po.default_light()])[:n_lights]
+    tfs = po.animation_transforms(45)
+    want = po.render_frame_sampled(meshes, tfs, po.default_camera(), ls, spp, 7, 120, 68)
+    got = em_default.render_sampled(po.default_camera(), ls, tfs, spp, 7, 120, 68)
+    assert np.array_equal(got["rgb"], want.rgb)
+    assert np.array_equal(got["hit_id"], want.hit_id)
+    for k in ("primary_rays", "shadow_rays", "hit_pixels", "shadowed_pixels"):
+        assert got["counters"][k] == want.counters[k], k
+    assert want.counters["primary_rays"] == 120 * 68 * spp
+    assert want.counters["shadow_rays"] == want.counters["hit_pixels"] * n_lights
+
+
+def test_more_samples_smooth_edges_and_seed_matters(po, meshes):
+    tfs = po.animation_transforms(0)
+    cam, ls = po.default_camera(), [po.default_light()]
+    one = po.render_frame_sampled(meshes, tfs, cam, ls, 1, 0, 96, 54).rgb.astype(np.int32)
+    many = po.render_frame_sampled(meshes, tfs, cam, ls, 16, 0, 96, 54).rgb.astype(np.int32)
+    other = po.render_frame_sampled(meshes, tfs, cam, ls, 16, 1, 96, 54).rgb.astype(np.int32)
+    assert not np.array_equal(many, other)                    # the seed changes the jitter
+    assert np.abs(many - one).mean() < 25                     # same picture
+    # horizontal gradients are softer with 16 samples per pixel
+    assert np.abs(np.diff(many, axis=1)).mean() < np.abs(np.diff(one, axis=1)).mean()
+
+
+def test_second_light_only_adds_light(po, meshes):
+    tfs = po.animation_transforms(30)
+    ls = lights3(po)
+    a = po.render_frame_sampled(meshes, tfs, po.default_camera(), ls[:1], 1, 0, 96, 54).rgb
+    b = po.render_frame_sampled(meshes, tfs, po.default_camera(), ls[:2], 1, 0, 96, 54).rgb
+    assert (b.astype(np.int32) >= a.astype(np.int32)).all() and (b > a).any()
+
+
+# ------------------------------------------------------------------------------------------ GPU
+
+@pytest.fixture(scope="module")
+def gscene(meshes):
+    from raytracer_amd import capi
+    c = capi.Context(0)
+    for m in meshes:
+        c.upload_mesh(m.tris, m.nodes, m.rgba)
+    yield c
+    c.close()
+
+
+def to_capi(capi, po, tfs, ls):
+    t = [capi.Transform(capi.Vec3(*x.position.tup()), capi.Vec3(*x.rotation.tup())) for x in tfs]
+    l = [capi.Light(capi.Vec3(*x.direction.tup()), capi.Vec3(*x.color.tup())) for x in ls]
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    return cam, t, l
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spp,n_lights,size", [(1, 1, (240, 135)), (4, 2, (333, 211)), (16, 3, (160, 90)), (64, 4, (33, 17)), (2, 1, (1, 1))])
+def test_gpu_sampled_equals_restatement(gscene, po, meshes, spp, n_lights, size):
+    import torch
+    from raytracer_amd import capi
+    w, h = size
+    ls = (lights3(po) + [po.default_light()])[:n_lights]
+    tfs = po.animation_transforms(45)
+    want = po.render_frame_sampled(meshes, tfs, po.default_camera(), ls, spp, 99, w, h)
+    cam, t, l = to_capi(capi, po, tfs, ls)
+    rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    hid = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+    for block in (64, 256):
+        gscene.set_option("block", block)
+        rgb.zero_()
+        torch.cuda.synchronize()          # the fills above ran on torch's stream, the launches below use another one
+        gscene.render_sampled(cam, l, t, w, h, spp, 99, rgb, hit_id=hid, flags=capi.RT_FLAG_COUNT_WORK)
+        gscene.sync()
+        assert np.array_equal(rgb.cpu().numpy(), want.rgb), (block, int((rgb.cpu().numpy() != want.rgb).any(axis=-1).sum()))
+        assert np.array_equal(hid.cpu().numpy(), want.hit_id)
+        c = gscene.last_counters()
+        for k in ("primary_rays", "shadow_rays", "hit_pixels", "shadowed_pixels"):
+            assert c[k] == want.counters[k], k
+    gscene.set_option("block", 64)
+
+
+@pytest.mark.gpu
+def test_gpu_sampled_one_sample_one_light_equals_render_frame_at_4k(gscene, po):
+    """At 3840x2160 (the size of the stress configuration) the sampled kernel with one sample and one light
+    writes the bytes of the plain frame kernel."""
+    import torch
+    from raytracer_amd import capi
+    w, h = 3840, 2160
+    tfs = po.animation_transforms(0)
+    cam, t, l = to_capi(capi, po, tfs, [po.default_light()])
+    a = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    b = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()          # the fills above ran on torch's stream, the launches below use another one
+    gscene.render(cam, l[0], t, w, h, a)
+    gscene.render_sampled(cam, l, t, w, h, 1, 5, b)
+    gscene.sync()
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_gpu_sampled_argument_errors(gscene, po):
+    import torch
+    from raytracer_amd import capi
+    cam, t, l = to_capi(capi, po, po.animation_transforms(0), lights3(po))
+    rgb = torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda:0")
+    for kwargs in (dict(spp=0), dict(spp=capi.RT_MAX_SAMPLES + 1), dict(lights=[]), dict(lights=l + l),
+                   dict(flags=capi.RT_FLAG_REFERENCE_ORDER), dict(tfs=t[:2])):
+        with pytest.raises(capi.RtError):
+            gscene.render_sampled(cam, kwargs.get("lights", l), kwargs.get("tfs", t), 8, 8, kwargs.get("spp", 2), 0, rgb,
+                                  flags=kwargs.get("flags", 0))

@@ -139,6 +139,7 @@ def test_gpu_render_then_upscale_full_size(gctx, po, meshes, golden_up_hashes):
             fs, os_ = w * h * 3 + 64, sw * sh + 32
             rgb = torch.zeros(2 * fs, dtype=torch.uint8, device=dev)
             argb = torch.full((2 * os_,), 0x01020304, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()          # the fills above ran on torch's stream, the launches below use another one
             stream = torch.cuda.Stream(device=dev)
             gctx.render_frames(cam, light, [tfs, tfs], w, h, rgb, frame_stride=fs, stream=stream.cuda_stream)
             gctx.upscale_frames(rgb, 2, w, h, sw, sh, argb, frame_stride=fs, out_stride=os_, stream=stream.cuda_stream)
