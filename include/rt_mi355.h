@@ -196,7 +196,8 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * 2 primary rays only), "budget" (variant 4: node visits one lane spends on a pixel before the pixel is
  * handed to the cooperative pass), "resident_budget" (variants 5..9: bytes of small meshes staged in LDS),
  * "batch_chunk" (rt_render_frames: consecutive tiles of one frame before the same tiles of the next
- * frame; 0 = four tile rows).
+ * frame; 0 = four tile rows), "xcd_swizzle" (rt_render_frames: 1 = each XCD gets runs of eight neighbouring
+ * tiles, default; 0 = every eighth tile).
  * Every setting produces the same image.  Read-only: "n_variants", "default_variant".
  * Unknown names give RT_ERR_INVALID. */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);

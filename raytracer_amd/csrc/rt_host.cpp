@@ -61,6 +61,7 @@ struct rt_ctx {
     int timing = 1;
     int budget = 48;               // two-pass variant: node visits per pixel before it is deferred
     int resident_budget = (int)kResidentBudget;   // bytes of small meshes staged in LDS by the lean kernels
+    int xcd_swizzle = 1;           // rt_render_frames: give each XCD runs of 8 neighbouring tiles
     int batch_chunk = 0;           // rt_render_frames: consecutive tiles of one frame before the next frame's; 0 = four tile rows
     int coop = 1;                  // cooperative rendering of the big meshes' screen area (variant 3)
     // rt_render_frames: per-frame constants travel through a ring of staging slots (pinned host
@@ -486,7 +487,7 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light
     RT_HIP(ctx, hipMemcpyAsync(d, h, (size_t)n_frames * sizeof(FrameArgs), hipMemcpyHostToDevice, s));
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
     hipError_t le = launch_batch(d, n_frames, width, height, S, (uint8_t*)d_rgb, frame_stride, first_row,
-                                 ctx->batch_chunk > 0 ? ctx->batch_chunk : 4 * ((width + 7) / 8), ctx->cfg.block, s);
+                                 ctx->batch_chunk > 0 ? ctx->batch_chunk : (4 * ((width + 7) / 8) + 63) / 64 * 64, ctx->xcd_swizzle, ctx->cfg.block, s);
     if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
     RT_HIP(ctx, hipEventRecord(ctx->batch_done[slot], s));
@@ -649,6 +650,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     }
     if (!strcmp(name, "timing")) { ctx->timing = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "coop")) { ctx->coop = value; return RT_OK; }
+    if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "batch_chunk")) {
         if (value < 0 || value > (1 << 20)) return fail(ctx, RT_ERR_INVALID, "batch_chunk out of range");
         ctx->batch_chunk = value; return RT_OK;

@@ -38,7 +38,7 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
 // scanned starting at first_row; `chunk` consecutive tiles of a frame are followed by the same tiles
 // of the next frame.  block: 64 or 256.
 hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb, size_t frame_stride,
-                        int first_row, int chunk, int block, hipStream_t stream);
+                        int first_row, int chunk, int swizzle, int block, hipStream_t stream);
 
 // Enqueues one sampled frame (X.spp camera rays per pixel, X.n_lights lights).  O.rgb is required,
 // O.hit_id optional (sample 0), the other planes are not written.  block: 64 or 256.

@@ -267,13 +267,17 @@ static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const Outp
 template <int BLOCK, int DEPTH, uint32_t LB>
 __global__ void __launch_bounds__(BLOCK) render_batch(const FrameArgs* __restrict__ frames, const int n_frames, const SceneArgs S,
                                                       uint8_t* __restrict__ rgb_base, const unsigned long long frame_stride,
-                                                      const int first_row, const int chunk) {
+                                                      const int first_row, const int chunk, const int xcd_swizzle) {
     __shared__ uint32_t lds_stack[DEPTH * BLOCK];
     LdsStack<BLOCK> stack;
     stack.init(&lds_stack[threadIdx.x]);
     GlobalNodes nodes; nodes.all = S.pairs;
 
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)));
+    int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)));
+    // Workgroups go to the 8 XCDs round robin.  With one wave per workgroup, transposing every run
+    // of 64 waves as an 8x8 block gives each XCD 8 neighbouring tiles of a row instead of every
+    // eighth tile, so the pixels of one cache line (five tiles wide) are written through one L2.
+    if (BLOCK == 64 && xcd_swizzle) wave = (wave & ~63) | ((wave & 7) << 3) | ((wave >> 3) & 7);
     // `chunk` consecutive tiles of one frame, then the same tiles of the next frame, ...
     const int group = wave / (chunk * n_frames);
     const int within = wave - group * (chunk * n_frames);
@@ -298,29 +302,30 @@ __global__ void __launch_bounds__(BLOCK) render_batch(const FrameArgs* __restric
 
 template <int BLOCK, int DEPTH>
 static hipError_t launch_batch_t(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb,
-                                 size_t frame_stride, int first_row, int chunk, hipStream_t stream) {
+                                 size_t frame_stride, int first_row, int chunk, int swizzle, hipStream_t stream) {
     const long long tiles = (long long)((width + 7) / 8) * ((height + 7) / 8);
-    const long long waves = (tiles + chunk - 1) / chunk * chunk * n_frames;
+    long long waves = (tiles + chunk - 1) / chunk * chunk * n_frames;
+    waves = (waves + 63) / 64 * 64;
     const int waves_per_block = BLOCK / 64;
     const long long blocks = (waves + waves_per_block - 1) / waves_per_block;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((render_batch<BLOCK, DEPTH, kLeafBatch>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, d_frames, n_frames, S, rgb,
-                       (unsigned long long)frame_stride, first_row, chunk);
+                       (unsigned long long)frame_stride, first_row, chunk, swizzle);
     return hipGetLastError();
 }
 
 hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb, size_t frame_stride,
-                        int first_row, int chunk, int block, hipStream_t stream) {
+                        int first_row, int chunk, int swizzle, int block, hipStream_t stream) {
     if (n_frames <= 0 || width <= 0 || height <= 0 || !d_frames || !rgb) return hipErrorInvalidValue;
     const int tiles_y = (height + 7) / 8;
     if (first_row < 0 || first_row >= tiles_y) first_row = 0;
     if (chunk < 1) chunk = 1;
     if (S.stack_entries <= 16) {
-        if (block == 64) return launch_batch_t<64, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, stream);
-        return launch_batch_t<256, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, stream);
+        if (block == 64) return launch_batch_t<64, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, stream);
+        return launch_batch_t<256, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, stream);
     }
-    if (block == 64) return launch_batch_t<64, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, stream);
-    return launch_batch_t<256, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, stream);
+    if (block == 64) return launch_batch_t<64, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, stream);
+    return launch_batch_t<256, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -133,16 +133,23 @@ int read_floats(const char* p, float* out, int n) {
     return got;
 }
 
-bool read_corner(const char*& p, long idx[3]) {
+// One face corner: "v", "v/vt", "v//vn" or "v/vt/vn".  Missing parts are reported as 0 (OBJ indices
+// start at 1); negative indices count back from the end of their list.
+bool read_corner(const char*& p, long idx[3], size_t n_pos, size_t n_uv, size_t n_nor) {
+    idx[0] = idx[1] = idx[2] = 0;
+    const size_t counts[3] = {n_pos, n_uv, n_nor};
     for (int k = 0; k < 3; k++) {
         char* end = nullptr;
-        idx[k] = strtol(p, &end, 10);
-        if (end == p) return false;
-        p = end;
-        if (k < 2) { if (*p != '/') return false; p++; }
+        const long v = strtol(p, &end, 10);
+        if (end != p) { idx[k] = v < 0 ? (long)counts[k] + v + 1 : v; p = end; }
+        else if (k == 0) return false;
+        if (*p != '/') break;
+        p++;
     }
     return true;
 }
+
+int g_obj_mode = 0;      // 0: the reference's reader; 1: tolerant reader (rt_host_set_obj_mode)
 
 }  // namespace
 
@@ -206,9 +213,10 @@ Mesh create_mesh(const char* obj_filename, const char* texture_filename) {      
     std::vector<Vec3> pos, nor;
     std::vector<Vec2> uv;
     std::vector<Triangle> tris;
-    char buf[4096];
-    while (fgets(buf, sizeof buf, f)) {
-        const char* p = buf;
+    char* line = nullptr;        // getline: no limit on the length of a line (the reference's is 255 characters)
+    size_t cap = 0;
+    while (getline(&line, &cap, f) >= 0) {
+        const char* p = line;
         if (p[0] == 'v' && p[1] == ' ') {
             float v[3] = {0, 0, 0}; read_floats(p + 2, v, 3); pos.push_back(Vec3{v[0], v[1], v[2]});
         } else if (p[0] == 'v' && p[1] == 't') {
@@ -216,21 +224,47 @@ Mesh create_mesh(const char* obj_filename, const char* texture_filename) {      
         } else if (p[0] == 'v' && p[1] == 'n') {
             float v[3] = {0, 0, 0}; read_floats(p + 3, v, 3); nor.push_back(Vec3{v[0], v[1], v[2]});
         } else if (p[0] == 'f') {
-            long c[3][3];
-            const char* q = skip_ws(p + 1);
-            bool ok = true;
-            for (int k = 0; k < 3 && ok; k++) { q = skip_ws(q); ok = read_corner(q, c[k]); }
-            for (int k = 0; k < 3 && ok; k++)
-                ok = c[k][0] >= 1 && (size_t)c[k][0] <= pos.size() && c[k][1] >= 1 && (size_t)c[k][1] <= uv.size() &&
-                     c[k][2] >= 1 && (size_t)c[k][2] <= nor.size();
-            if (!ok) { fprintf(stderr, "%s: skipping face the reader cannot use: %s", obj_filename, buf); continue; }
-            Triangle t;
-            t.v0 = pos[(size_t)c[0][0] - 1]; t.v1 = pos[(size_t)c[1][0] - 1]; t.v2 = pos[(size_t)c[2][0] - 1];
-            t.t0 = uv[(size_t)c[0][1] - 1];  t.t1 = uv[(size_t)c[1][1] - 1];  t.t2 = uv[(size_t)c[2][1] - 1];
-            t.n0 = nor[(size_t)c[0][2] - 1]; t.n1 = nor[(size_t)c[1][2] - 1]; t.n2 = nor[(size_t)c[2][2] - 1];
-            tris.push_back(t);
+            // corners of the face
+            std::vector<long> c;
+            const char* q = p + 1;
+            for (;;) {
+                q = skip_ws(q);
+                long idx[3];
+                if (!read_corner(q, idx, pos.size(), uv.size(), nor.size())) break;
+                c.insert(c.end(), idx, idx + 3);
+            }
+            const size_t corners = c.size() / 3;
+            bool ok = corners >= 3;
+            for (size_t k = 0; k < corners && ok; k++) {
+                ok = c[3 * k] >= 1 && (size_t)c[3 * k] <= pos.size() && c[3 * k + 1] >= 0 && (size_t)c[3 * k + 1] <= uv.size() &&
+                     c[3 * k + 2] >= 0 && (size_t)c[3 * k + 2] <= nor.size();
+                // the reference reads exactly "v/vt/vn" three times (mesh.c:59-63): every part must be there
+                if (g_obj_mode == 0 && k < 3 && (c[3 * k + 1] == 0 || c[3 * k + 2] == 0)) ok = false;
+            }
+            if (!ok) { fprintf(stderr, "%s: skipping face the reader cannot use: %s", obj_filename, line); continue; }
+            // reference reader: the first three corners are the triangle, further corners are ignored;
+            // tolerant reader: a fan over all corners
+            const size_t fan = g_obj_mode == 0 ? 1 : corners - 2;
+            for (size_t k = 0; k < fan; k++) {
+                const size_t i0 = 0, i1 = k + 1, i2 = k + 2;
+                Triangle t;
+                t.v0 = pos[(size_t)c[3 * i0] - 1]; t.v1 = pos[(size_t)c[3 * i1] - 1]; t.v2 = pos[(size_t)c[3 * i2] - 1];
+                const Vec2 no_uv = {0.0f, 0.0f};
+                t.t0 = c[3 * i0 + 1] ? uv[(size_t)c[3 * i0 + 1] - 1] : no_uv;
+                t.t1 = c[3 * i1 + 1] ? uv[(size_t)c[3 * i1 + 1] - 1] : no_uv;
+                t.t2 = c[3 * i2 + 1] ? uv[(size_t)c[3 * i2 + 1] - 1] : no_uv;
+                // a corner without a normal gets the triangle's geometric normal
+                const rt::F3 a0 = rt::f3(t.v0.x, t.v0.y, t.v0.z), a1 = rt::f3(t.v1.x, t.v1.y, t.v1.z), a2 = rt::f3(t.v2.x, t.v2.y, t.v2.z);
+                const rt::F3 g = rt::unit(rt::cross(rt::sub(a1, a0), rt::sub(a2, a0)));
+                const Vec3 face_n = {g.x, g.y, g.z};
+                t.n0 = c[3 * i0 + 2] ? nor[(size_t)c[3 * i0 + 2] - 1] : face_n;
+                t.n1 = c[3 * i1 + 2] ? nor[(size_t)c[3 * i1 + 2] - 1] : face_n;
+                t.n2 = c[3 * i2 + 2] ? nor[(size_t)c[3 * i2 + 2] - 1] : face_n;
+                tris.push_back(t);
+            }
         }
     }
+    free(line);
     fclose(f);
     mesh.triangles = (Triangle*)malloc(sizeof(Triangle) * (tris.empty() ? 1 : tris.size()));
     if (!mesh.triangles) return mesh;
@@ -390,6 +424,8 @@ int rt_host_upscale_frame(Scene* scene, int index, uint32_t* argb) {            
     st->last_status = rc;
     return rc;
 }
+
+void rt_host_set_obj_mode(int tolerant) { g_obj_mode = tolerant ? 1 : 0; }
 
 int rt_host_write_ppm(const Scene* scene, int index, const char* filename) {
     if (!scene || !filename || index < 0 || index >= scene->frame_count) return RT_ERR_INVALID;

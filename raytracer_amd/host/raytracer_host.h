@@ -98,6 +98,12 @@ int rt_host_render_debug(Scene* scene, int32_t* hit_id, float* hit_t, uint8_t* s
 void rt_host_demo_animation(int frame, Transform* drone, Transform* treasure);
 /* Writes frame `index` as a binary PPM (P6). */
 int rt_host_write_ppm(const Scene* scene, int index, const char* filename);
+/* OBJ reader of create_mesh.  0 (default): what the reference reads (mesh.c:41-76) -- "f v/vt/vn v/vt/vn v/vt/vn",
+ * corners after the third ignored, faces it cannot use skipped with a message instead of read out of bounds.
+ * 1: tolerant -- faces with more than three corners become a triangle fan, "v", "v/vt" and "v//vn" corners are
+ * accepted (texture coordinate 0,0 / geometric normal where missing), negative indices count from the end.
+ * In both modes lines and element counts are unbounded. */
+void rt_host_set_obj_mode(int tolerant);
 /* The size and the pixels save_scene hands to its encoder for one frame (scene.c:164-165, 188-202):
  * argb receives scaled_width*scaled_height words, 0xFF000000 | r<<16 | g<<8 | b, upscaled on the GPU. */
 int rt_host_scaled_size(const Scene* scene, int* scaled_width, int* scaled_height);

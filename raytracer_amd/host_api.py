@@ -80,6 +80,7 @@ EXPORTS = [
     "sample_mesh_texture", "create_bvh_node", "create_bvh", "destroy_bvh_node", "destroy_bvh", "create_camera",
     "create_directional_light", "rt_host_set_device", "rt_host_last_status", "rt_host_render_debug",
     "rt_host_demo_animation", "rt_host_write_ppm", "rt_host_scaled_size", "rt_host_upscale_frame",
+    "rt_host_set_obj_mode",
 ]
 
 _lib = None
@@ -135,6 +136,8 @@ def lib():
         L.rt_host_demo_animation.restype = None
         L.rt_host_demo_animation.argtypes = [C.c_int, C.POINTER(Transform), C.POINTER(Transform)]
         L.rt_host_write_ppm.argtypes = [C.POINTER(Scene), C.c_int, C.c_char_p]
+        L.rt_host_set_obj_mode.restype = None
+        L.rt_host_set_obj_mode.argtypes = [C.c_int]
         L.rt_host_scaled_size.argtypes = [C.POINTER(Scene), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rt_host_upscale_frame.argtypes = [C.POINTER(Scene), C.c_int, C.c_void_p]
         for name in EXPORTS:

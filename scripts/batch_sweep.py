@@ -27,7 +27,8 @@ def main():
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--total", type=int, default=96, help="frames rendered per measurement")
     p.add_argument("--rounds", type=int, default=3)
-    p.add_argument("--chunks", default="1", help="comma list: consecutive tiles of one frame before the next frame's")
+    p.add_argument("--swizzle", default="1", help="comma list of 0/1: XCD-aware tile order")
+    p.add_argument("--chunks", default="0", help="comma list: consecutive tiles of one frame before the next frame's")
     p.add_argument("--out", default="gpurun_out/batch.json")
     a = p.parse_args()
     from raytracer_amd import demo
@@ -60,9 +61,10 @@ def main():
     print(json.dumps({"batch_equals_single": ok}), flush=True)
 
     rows = []
-    for block, chunk in [(int(b), int(q)) for b in a.blocks.split(",") for q in a.chunks.split(",")]:
+    for block, chunk, swz in [(int(b), int(q), int(z)) for b in a.blocks.split(",") for q in a.chunks.split(",") for z in a.swizzle.split(",")]:
         ctx.set_option("block", block)
         ctx.set_option("batch_chunk", chunk)
+        ctx.set_option("xcd_swizzle", swz)
         for ns in [int(s) for s in a.streams.split(",")]:
             for nb in [int(b) for b in a.batches.split(",")]:
                 launches = max(a.total // nb, 1)
@@ -78,7 +80,7 @@ def main():
                     torch.cuda.synchronize(dev)
                     if r:
                         ts.append((time.perf_counter() - t0) * 1e3 / (launches * nb))
-                row = {"block": block, "chunk": chunk, "streams": ns, "batch": nb, "ms_per_frame_median": round(float(np.median(ts)), 4),
+                row = {"block": block, "chunk": chunk, "swizzle": swz, "streams": ns, "batch": nb, "ms_per_frame_median": round(float(np.median(ts)), 4),
                        "ms_per_frame_min": round(float(np.min(ts)), 4)}
                 rows.append(row)
                 print(json.dumps(row), flush=True)

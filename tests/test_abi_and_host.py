@@ -203,3 +203,89 @@ def test_demo_animation_equals_reference_driver(host, po):
         for got, w in ((d, want[0]), (t, want[1])):
             g = np.array([got.position.x, got.position.y, got.position.z, got.rotation.x, got.rotation.y, got.rotation.z], np.float32)
             assert np.array_equal(bits(g), bits(np.array(w.position.tup() + w.rotation.tup(), np.float32)))
+
+
+OBJ_MIXED = """# comment
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0.5 0.5 1
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 0 1
+f 1/1/1 2/2/1 3/3/1
+f 1/1/1 2/2/1 3/3/1 4/4/1
+f 1//1 2//1 5//1
+f 1/1 2/2 5/3
+f 1 4 5
+f -5/-4/-1 -4/-3/-1 -1/-2/-1
+f 1/1/1 2/2/1
+f 1/1/1 2/2/1 9/3/1
+""" + "f 1/1/1 2/2/1 3/3/1 " + " " * 5000 + "\n"
+
+
+def test_obj_reader_modes(host, tmp_path):
+    """Default mode reads what the reference reads (mesh.c:41-76: three v/vt/vn corners, the rest of the line ignored);
+    the tolerant mode adds fans, optional vt/vn and negative indices.  Both accept long lines."""
+    H = host.lib()
+    obj = tmp_path / "mixed.obj"
+    obj.write_text(OBJ_MIXED)
+    tex = os.path.join(host.ASSETS, "ground.webp").encode()
+    try:
+        m = H.create_mesh(str(obj).encode(), tex)
+        t = host.mesh_triangles(m)
+        # full triangle, first three corners of the quad, the negative-index triangle (v1 v2 v5), the long line
+        assert t.shape[0] == 4
+        assert np.array_equal(t[0, 0:9], [0, 0, 0, 1, 0, 0, 1, 1, 0]) and np.array_equal(t[1], t[0])
+        assert np.array_equal(t[2, 0:9], [0, 0, 0, 1, 0, 0, 0.5, 0.5, 1])
+        assert np.array_equal(t[2, 9:15], [0, 0, 1, 0, 1, 1])            # vt -4 -3 -2 of four = 1 2 3
+        H.destroy_mesh(C.byref(m))
+
+        H.rt_host_set_obj_mode(1)
+        m = H.create_mesh(str(obj).encode(), tex)
+        t = host.mesh_triangles(m)
+        assert t.shape[0] == 1 + 2 + 1 + 1 + 1 + 1 + 1                     # the two malformed faces are still skipped
+
+        def rows(v9):                                                       # the BVH build reorders more than 4 triangles
+            return [r for r in t if np.array_equal(r[0:9], np.array(v9, np.float32))]
+        assert len(rows([0, 0, 0, 1, 0, 0, 1, 1, 0])) == 3                 # the triangle, the quad's first half, the long line
+        assert len(rows([0, 0, 0, 1, 1, 0, 0, 1, 0])) == 1                 # second triangle of the fan: corners 1 3 4
+        apex = rows([0, 0, 0, 1, 0, 0, 0.5, 0.5, 1])                       # v//vn, v/vt and the negative-index face
+        assert len(apex) == 3
+        n = np.cross(np.array([1, 0, 0.0]), np.array([0.5, 0.5, 1.0]))
+        n /= np.linalg.norm(n)
+        kinds = set()
+        for r in apex:
+            if np.array_equal(r[9:15], [0, 0, 0, 0, 0, 0]):               # v//vn: no texture coordinates, the file's normal
+                assert np.array_equal(r[15:24], [0, 0, 1] * 3)
+                kinds.add("v//vn")
+            elif np.allclose(r[15:18], n, atol=1e-6):                     # v/vt: geometric normal
+                assert np.array_equal(r[9:15], [0, 0, 1, 0, 1, 1])
+                kinds.add("v/vt")
+            else:                                                         # negative indices, everything given
+                assert np.array_equal(r[9:15], [0, 0, 1, 0, 1, 1]) and np.array_equal(r[15:24], [0, 0, 1] * 3)
+                kinds.add("negative")
+        assert kinds == {"v//vn", "v/vt", "negative"}
+        bare = rows([0, 0, 0, 0, 1, 0, 0.5, 0.5, 1])                       # "f 1 4 5"
+        g = np.cross([0, 1, 0], [0.5, 0.5, 1.0])
+        assert len(bare) == 1 and np.allclose(bare[0][15:24].reshape(3, 3), g / np.linalg.norm(g), atol=1e-6)
+        assert m.bvh.root and int(m.bvh.triangle_count) == t.shape[0]
+        H.destroy_mesh(C.byref(m))
+    finally:
+        H.rt_host_set_obj_mode(0)
+
+
+def test_obj_reader_modes_agree_on_reference_assets(host, golden_hashes):
+    import hashlib
+    H = host.lib()
+    try:
+        for mode in (0, 1):
+            H.rt_host_set_obj_mode(mode)
+            m = H.create_mesh(os.path.join(host.ASSETS, "drone.obj").encode(), os.path.join(host.ASSETS, "drone.webp").encode())
+            assert hashlib.sha256(host.mesh_triangles(m).tobytes()).hexdigest() == golden_hashes["meshes"]["drone"]["triangles_post_sha256"]
+            H.destroy_mesh(C.byref(m))
+    finally:
+        H.rt_host_set_obj_mode(0)
