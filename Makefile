@@ -15,7 +15,7 @@ oracle:
 
 emul: tests/host_emul/libemul.so
 
-tests/host_emul/libemul.so: tests/host_emul/emul.cpp raytracer_amd/csrc/rt_pixel.h raytracer_amd/csrc/rt_sampled.h raytracer_amd/csrc/rt_bicubic.h raytracer_amd/csrc/rt_pack.h raytracer_amd/csrc/rt_exact.h raytracer_amd/csrc/rt_layout.h include/rt_mi355.h
+tests/host_emul/libemul.so: tests/host_emul/emul.cpp raytracer_amd/csrc/rt_pixel.h raytracer_amd/csrc/rt_sampled.h raytracer_amd/csrc/rt_instanced.h raytracer_amd/csrc/rt_bicubic.h raytracer_amd/csrc/rt_pack.h raytracer_amd/csrc/rt_exact.h raytracer_amd/csrc/rt_layout.h include/rt_mi355.h
 	$(CXX) -O2 -std=c++17 -ffp-contract=off -fopenmp -fPIC -shared -Wall -Wextra -o $@ tests/host_emul/emul.cpp -lm
 
 clean:

@@ -36,6 +36,7 @@ typedef enum {
 #define RT_MAX_TREE_DEPTH    30         /* deepest BVH the traversal stack covers */
 #define RT_MAX_MESH_TRIS     (1 << 24)  /* triangles per mesh */
 #define RT_MAX_BATCH         16         /* frames per rt_render_frames call */
+#define RT_MAX_INSTANCES     (1 << 20)  /* placed meshes per rt_render_frame_instanced call */
 #define RT_MAX_LIGHTS        4          /* lights per rt_render_frame_sampled call */
 #define RT_MAX_SAMPLES       64         /* camera rays per pixel in rt_render_frame_sampled */
 
@@ -153,6 +154,24 @@ int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light
                             const rt_transform* transforms, int32_t n_transforms,
                             int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed,
                             uint32_t flags, void* d_rgb, void* d_hit_id, void* stream);
+
+/* render_scene for a scene whose mesh list is long: the reference's Scene.meshes may hold any number of
+ * Mesh values (add_mesh_to_scene, scene.c:31-35), for example the same triangles and BVH under thousands of
+ * transforms, and tests every ray against every one of them (scene.c:72-108, 124-139).  Here the uploaded
+ * meshes are the distinct geometries and `instances` is the scene's mesh list, in its order: instance i is
+ * uploaded mesh instances[i].mesh placed by instances[i].transform.  The result is what render_scene gives
+ * for that list (closest hit, the earlier list entry winning equal distances; shadow = any entry blocks).
+ * A hierarchy over the instances' world-space boxes, rebuilt on the host for every call, proposes the
+ * instances a ray is tested against.  d_hit_instance (optional) receives the list index of the hit
+ * (-1 = miss), d_hit_tri (optional) the triangle index inside its mesh, d_hit_t / d_shadow as in
+ * rt_render_frame.  Not limited by RT_MAX_MESHES: n_instances <= RT_MAX_INSTANCES; the uploaded
+ * meshes themselves are still at most RT_MAX_MESHES. */
+typedef struct { int32_t mesh; rt_transform transform; } rt_instance;
+int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
+                              const rt_instance* instances, int32_t n_instances,
+                              int32_t width, int32_t height, uint32_t flags,
+                              void* d_rgb, void* d_hit_instance, void* d_hit_tri, void* d_hit_t, void* d_shadow,
+                              void* stream);
 
 /* Same, for callers that hold host buffers (what scene->frames[current_frame] is in the
  * reference): renders into context-owned device planes, waits, and copies back. */

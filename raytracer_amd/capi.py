@@ -41,6 +41,10 @@ class Light(C.Structure):
     _fields_ = [("direction", Vec3), ("color", Vec3)]
 
 
+class Instance(C.Structure):
+    _fields_ = [("mesh", C.c_int32), ("transform", Transform)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("primary_rays", "shadow_rays", "slab_tests", "tri_tests", "hit_pixels", "shadowed_pixels")]
@@ -58,7 +62,7 @@ EXPORTS = [
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
-    "rt_render_frame_sampled",
+    "rt_render_frame_sampled", "rt_render_frame_instanced",
 ]
 
 _lib = None
@@ -109,6 +113,8 @@ def lib():
                                        vp, C.c_size_t, vp]
         L.rt_render_frame_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, i32, i32,
                                               u32, u32, vp, vp, vp]
+        L.rt_render_frame_instanced.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Instance), i32, i32, i32, u32,
+                                                vp, vp, vp, vp, vp, vp]
         L.rt_scaled_size.argtypes = [i32, i32, C.c_float, C.POINTER(i32), C.POINTER(i32)]
         L.rt_upscale_frames.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
         L.rt_upscale_frame_host.argtypes = [vp, vp, i32, i32, i32, i32, vp]
@@ -267,6 +273,23 @@ class Context:
         self._check(lib().rt_render_frame_sampled(self._h, C.byref(camera), larr, len(lights), arr, len(transforms), int(width),
                                                   int(height), int(samples_per_pixel), int(seed) & 0xFFFFFFFF, int(flags),
                                                   _dev_ptr(rgb), _dev_ptr(hit_id), stream))
+
+    @staticmethod
+    def make_instances(mesh_ids: Sequence[int], transforms: Sequence[Transform]):
+        """ctypes array of rt_instance for render_instanced (build once, reuse across calls)."""
+        arr = (Instance * max(len(mesh_ids), 1))()
+        for i, (m, t) in enumerate(zip(mesh_ids, transforms)):
+            arr[i].mesh = int(m)
+            arr[i].transform = t
+        return arr, len(mesh_ids)
+
+    def render_instanced(self, camera: Camera, light: Light, instances, width: int, height: int, rgb, hit_instance=None,
+                         hit_tri=None, hit_t=None, shadow=None, flags: int = 0, stream: Optional[int] = None):
+        """rt_render_frame_instanced; `instances` is what make_instances returns."""
+        arr, n = instances
+        self._check(lib().rt_render_frame_instanced(self._h, C.byref(camera), C.byref(light), arr, n, int(width), int(height),
+                                                    int(flags), _dev_ptr(rgb), _dev_ptr(hit_instance), _dev_ptr(hit_tri),
+                                                    _dev_ptr(hit_t), _dev_ptr(shadow), stream))
 
     def upscale_frames(self, rgb, n_frames: int, width: int, height: int, scaled_width: int, scaled_height: int, argb,
                        frame_stride: Optional[int] = None, out_stride: Optional[int] = None, stream: Optional[int] = None):

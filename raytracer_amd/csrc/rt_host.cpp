@@ -17,6 +17,7 @@ using namespace rt;
 namespace {
 
 constexpr int kBatchSlots = 4;
+constexpr int kInstSlots = 2;
 
 struct DeviceMesh {
     std::vector<PairNode> pairs;   // host copy; the device copy lives in the scene's combined array
@@ -66,6 +67,14 @@ struct rt_ctx {
     int coop = 1;                  // cooperative rendering of the big meshes' screen area (variant 3)
     // rt_render_frames: per-frame constants travel through a ring of staging slots (pinned host
     // copy -> device copy on the caller's stream); a slot is reused once its event has completed.
+    // rt_render_frame_instanced: per call [MeshArgs x n][PairNode x n][order x n] staged through one of
+    // two slots (pinned host copy -> device copy on the caller's stream)
+    uint8_t* h_inst[kInstSlots] = {};
+    uint8_t* d_inst[kInstSlots] = {};
+    size_t inst_capacity[kInstSlots] = {};     // instances a slot holds
+    hipEvent_t inst_done[kInstSlots] = {};
+    bool inst_used[kInstSlots] = {};
+    unsigned inst_seq = 0;
     FrameArgs* h_batch = nullptr;
     FrameArgs* d_batch = nullptr;
     hipEvent_t batch_done[kBatchSlots] = {};
@@ -255,6 +264,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_batch, batch_bytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_batch, batch_bytes);
     for (int i = 0; i < kBatchSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->batch_done[i], hipEventDisableTiming);
+    for (int i = 0; i < kInstSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->inst_done[i], hipEventDisableTiming);
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) { ctx->cfg.queue = ctx->d_queue; ctx->cfg.n_cus = cus > 0 ? cus : 256; }
@@ -282,6 +292,14 @@ int rt_ctx_destroy(rt_ctx* ctx) {
         if (!ctx->batch_done[i]) continue;
         if (ctx->batch_used[i]) (void)hipEventSynchronize(ctx->batch_done[i]);
         (void)hipEventDestroy(ctx->batch_done[i]);
+    }
+    for (int i = 0; i < kInstSlots; i++) {
+        if (ctx->inst_done[i]) {
+            if (ctx->inst_used[i]) (void)hipEventSynchronize(ctx->inst_done[i]);
+            (void)hipEventDestroy(ctx->inst_done[i]);
+        }
+        if (ctx->h_inst[i]) (void)hipHostFree(ctx->h_inst[i]);
+        if (ctx->d_inst[i]) (void)hipFree(ctx->d_inst[i]);
     }
     if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -526,6 +544,80 @@ int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light
     hipError_t le = launch_sampled(A, X, S, O, ctx->cfg.block, s);
     if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
+    return RT_OK;
+}
+
+int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_instance* instances, int32_t n_instances,
+                              int32_t width, int32_t height, uint32_t flags, void* d_rgb, void* d_hit_instance, void* d_hit_tri,
+                              void* d_hit_t, void* d_shadow, void* stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!camera || !light || !d_rgb) return fail(ctx, RT_ERR_INVALID, "camera, light and d_rgb are required");
+    if (n_instances < 0 || (n_instances > 0 && !instances)) return fail(ctx, RT_ERR_INVALID, "bad instance list");
+    if (n_instances > RT_MAX_INSTANCES) return fail(ctx, RT_ERR_UNSUPPORTED, "more than RT_MAX_INSTANCES instances");
+    if (flags & RT_FLAG_REFERENCE_ORDER) return fail(ctx, RT_ERR_UNSUPPORTED, "RT_FLAG_REFERENCE_ORDER is not available for instanced scenes");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    for (int32_t i = 0; i < n_instances; i++)
+        if (instances[i].mesh < 0 || instances[i].mesh >= (int32_t)ctx->meshes.size()) return fail(ctx, RT_ERR_INVALID, "instance of a mesh that was not uploaded");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int cst = commit_scene(ctx);
+    if (cst != RT_OK) return cst;
+    const SceneArgs S = scene_args(ctx);
+
+    // staging slot, grown to the instance count
+    const int slot = (int)(ctx->inst_seq++ % (unsigned)kInstSlots);
+    if (ctx->inst_used[slot]) RT_HIP(ctx, hipEventSynchronize(ctx->inst_done[slot]));
+    const size_t n = (size_t)(n_instances > 0 ? n_instances : 1);
+    const size_t off_pairs = (n * sizeof(MeshArgs) + 63) & ~(size_t)63, off_order = off_pairs + n * sizeof(PairNode), total = off_order + ((n * sizeof(uint32_t) + 63) & ~(size_t)63);
+    if (n > ctx->inst_capacity[slot]) {
+        if (ctx->h_inst[slot]) (void)hipHostFree(ctx->h_inst[slot]);
+        if (ctx->d_inst[slot]) (void)hipFree(ctx->d_inst[slot]);
+        ctx->h_inst[slot] = nullptr; ctx->d_inst[slot] = nullptr; ctx->inst_capacity[slot] = 0;
+        RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_inst[slot], total, hipHostMallocDefault));
+        RT_HIP(ctx, hipMalloc((void**)&ctx->d_inst[slot], total));
+        ctx->inst_capacity[slot] = n;
+    }
+    uint8_t* h = ctx->h_inst[slot];
+    uint8_t* d = ctx->d_inst[slot];
+
+    FrameArgs A;
+    fill_frame(ctx, *camera, *light, nullptr, 0, width, height, flags, A);
+    MeshArgs* inst = reinterpret_cast<MeshArgs*>(h);
+    std::vector<InstanceBox> boxes;
+    std::vector<uint32_t> ids;
+    boxes.reserve((size_t)n_instances); ids.reserve((size_t)n_instances);
+    for (int32_t i = 0; i < n_instances; i++) {
+        inst[i] = ctx->meshes[(size_t)instances[i].mesh].proto;
+        fill_placement(instances[i].transform, A, inst[i]);
+        if (!inst[i].empty) { boxes.push_back(instance_box(instances[i].transform, inst[i].root_min, inst[i].root_max)); ids.push_back((uint32_t)i); }
+    }
+    Tlas T;
+    TlasBuilder(boxes, ids, T).run();
+    if (T.depth + 2 > kTlasStackDepth) return fail(ctx, RT_ERR_UNSUPPORTED, "instance hierarchy deeper than its stack");
+    if (!T.pairs.empty()) memcpy(h + off_pairs, T.pairs.data(), T.pairs.size() * sizeof(PairNode));
+    if (!T.order.empty()) memcpy(h + off_order, T.order.data(), T.order.size() * sizeof(uint32_t));
+    RT_HIP(ctx, hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
+
+    InstancedArgs I;
+    I.inst = reinterpret_cast<const MeshArgs*>(d);
+    I.n_inst = (int32_t)ids.size();
+    I.tlas_root = T.root_ref;
+    I.tlas = reinterpret_cast<const PairNode*>(d + off_pairs);
+    I.order = reinterpret_cast<const uint32_t*>(d + off_order);
+    memcpy(I.root_min, T.root_min, 12); memcpy(I.root_max, T.root_max, 12);
+    OutputPlanes O;
+    O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_instance; O.hit_t = (float*)d_hit_t; O.shadow = (uint8_t*)d_shadow;
+    O.counters = ctx->d_counters; O.tile_clock = nullptr;
+    if (flags & RT_FLAG_COUNT_WORK) {
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DeviceCounters), s));
+        ctx->counters_pending = true;
+    }
+    if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
+    hipError_t le = launch_instanced(A, I, S, O, (int32_t*)d_hit_tri, ctx->cfg.block, s);
+    if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
+    if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
+    RT_HIP(ctx, hipEventRecord(ctx->inst_done[slot], s));
+    ctx->inst_used[slot] = true;
     return RT_OK;
 }
 

@@ -1,0 +1,131 @@
+// rt_instanced.h -- one pixel of the frame loop for scenes with many placed meshes.
+//
+// The reference tests a ray against every mesh of the scene in order (scene.c:72-108) and keeps a hit
+// only if it is strictly closer than the closest so far, so its result is the minimum of
+// (t, mesh index) over the meshes' own closest hits.  Written like that it does not depend on the
+// order in which meshes are tried, and a mesh whose box the ray cannot reach need not be tried at
+// all.  Here a hierarchy over the instances' world-space boxes (padded, see the host builder)
+// proposes the instances; each proposed instance gets the reference's own test in its own space
+// (ray.c:5-22 transform, root box, BVH), and the winner is chosen by (t, instance index).
+// The shadow pass (scene.c:124-139) is "any instance blocks".
+#pragma once
+#include "rt_pixel.h"
+
+namespace rt {
+
+struct InstancedOut {
+    uint8_t r, g, b;
+    uint8_t shadow;      // 1 blocked, 0 lit, 255 no primary hit
+    int32_t inst;        // winning instance or -1
+    int32_t tri;         // its triangle or -1
+    float hit_t;
+    uint32_t hit, dark;
+};
+
+// World-space walk over the instance hierarchy; calls visit(instance index) for every instance whose
+// padded box the ray enters no farther than limit().  visit returns true to stop the walk.
+template <class TStack, class Visit, class Limit>
+RT_HD void walk_instances(const InstancedArgs& I, F3 o, F3 inv, TStack& ts, Limit limit, Visit visit) {
+    float entry;
+    if (I.n_inst <= 0 || !slab_t(o, inv, I.root_min, I.root_max, entry)) return;
+    const SlabRay sr = slab_ray(o, inv);
+    ts.clear();
+    uint32_t ref = I.tlas_root;
+    bool live = true;
+    while (live) {
+        while (live && !(ref & kLeafBit)) {
+            const PairNode N = I.tlas[ref];
+            float tl, tr;
+            bool hl, hr;
+            slab_pair(sr, N, tl, tr, hl, hr);
+            const float lim = limit();
+            hl = hl && !(tl > lim); hr = hr && !(tr > lim);
+            const bool left_first = !(tr < tl);
+            if (hl && hr) { ts.push(left_first ? N.rref : N.lref); ref = left_first ? N.lref : N.rref; }
+            else if (hl || hr) ref = hl ? N.lref : N.rref;
+            else if (ts.empty()) live = false;
+            else ref = ts.pop();
+        }
+        if (live) {
+            const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
+            for (uint32_t k = 0; k < count; k++)
+                if (visit(I.order[first + k])) return;
+            if (ts.empty()) live = false;
+            else ref = ts.pop();
+        }
+    }
+}
+
+template <bool COUNT, class Stack, class TStack, class Nodes, class Party>
+RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs& I, const Nodes& nodes, const Party& party, int px, int py,
+                                         Stack& stack, TStack& tstack, Work& work) {
+    InstancedOut out;
+    // ---- camera ray (camera.c:12-30) ----
+    const float fx = ((float)px + 0.5f) / (float)A.width;
+    const float fy = ((float)py + 0.5f) / (float)A.height;
+    const float rx = (2.0f * fx - 1.0f) * A.aspect * A.scale;
+    const float ry = (1.0f - 2.0f * fy) * A.scale;
+    const F3 wo = f3(A.cam_pos);
+    const F3 wd = unit(add(add(scale(f3(A.cam_right), rx), scale(f3(A.cam_up), ry)), f3(A.cam_fwd)));
+
+    // ---- closest hit over the instances ----
+    float closest = 1e30f;
+    int who = -1;
+    Hit best = no_hit();
+    walk_instances(I, wo, recip(wd), tstack, [&]() { return cull_limit(closest); }, [&](uint32_t i) {
+        const MeshArgs& M = I.inst[i];
+        const F3 ld = unit(xform_vector<4>(M.inv, wd));
+        Hit h = no_hit();
+        // a mesh that is a single leaf honours the bound inside the leaf (bvh.c:85): give it none, the
+        // comparison below decides
+        const float bound = (M.root_ref & kLeafBit) ? 1e30f : closest;
+        if (party.template closest<COUNT, false>(M, nodes, f3(M.cam_o), ld, recip(ld), bound, h, stack, work) &&
+            (h.t < closest || (h.t == closest && (int)i < who))) {
+            closest = h.t; who = (int)i; best = h;
+        }
+        return false;
+    });
+    out.hit_t = closest;
+    if (who < 0) {
+        out.r = out.g = out.b = 50; out.shadow = 255; out.inst = -1; out.tri = -1; out.hit = 0; out.dark = 0;
+        return out;
+    }
+    const MeshArgs& M = I.inst[who];
+    out.hit = 1; out.inst = who; out.tri = (int32_t)best.tri;
+
+    // ---- attributes, texel (scene.c:86-106, mesh.c:138-149) ----
+    const AttrRec& R = M.attrs[best.tri];
+    const float u = best.u, v = best.v;
+    const float w = 1.0f - u - v;
+    const float tu = w * R.t0[0] + u * R.t1[0] + v * R.t2[0];
+    const float tv = w * R.t0[1] + u * R.t1[1] + v * R.t2[1];
+    F3 n = unit(add(add(scale(f3(R.n0), w), scale(f3(R.n1), u)), scale(f3(R.n2), v)));
+    n = unit(xform_vector<3>(M.nrm, n));
+    const float su = tu - floorf(tu), sv = tv - floorf(tv);
+    const int tx = (int)(su * (float)(M.tex_w - 1));
+    const int ty = (int)(sv * (float)(M.tex_h - 1));
+    const uint32_t texel = M.texels[ty * M.tex_w + tx];
+    F3 color = f3((float)(texel & 0xFFu) / 255.0f, (float)((texel >> 8) & 0xFFu) / 255.0f, (float)((texel >> 16) & 0xFFu) / 255.0f);
+
+    // ---- shadow ray (scene.c:117-139): any instance ----
+    const F3 so = add(add(wo, scale(wd, closest)), scale(n, 0.001f));
+    const F3 L = f3(A.light_dir);
+    bool dark = false;
+    walk_instances(I, so, recip(L), tstack, []() { return 3.0e38f; }, [&](uint32_t i) {
+        const MeshArgs& S = I.inst[i];
+        const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);
+        dark = party.template any<COUNT, false>(S, nodes, lo, f3(S.lit_d), f3(S.lit_inv), stack, work);
+        return dark;
+    });
+    float diffuse = 0.2f;
+    if (!dark) diffuse = fmaxf(diffuse, dot(n, L));
+    color = scale(mul(color, f3(A.light_color)), diffuse);
+    out.r = (uint8_t)(fminf(color.x * 255.0f, 255.0f));
+    out.g = (uint8_t)(fminf(color.y * 255.0f, 255.0f));
+    out.b = (uint8_t)(fminf(color.z * 255.0f, 255.0f));
+    out.shadow = dark ? 1 : 0;
+    out.dark = dark ? 1 : 0;
+    return out;
+}
+
+}  // namespace rt

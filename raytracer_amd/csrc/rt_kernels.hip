@@ -22,6 +22,7 @@
 
 #include "rt_kernels.h"
 #include "rt_pixel.h"
+#include "rt_instanced.h"
 #include "rt_sampled.h"
 
 namespace rt {
@@ -181,6 +182,57 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
     } else {
         if (count) hipLaunchKernelGGL((render_sampled<64, true>), dim3(tiles), dim3(64), 0, stream, A, X, S, O);
         else       hipLaunchKernelGGL((render_sampled<64, false>), dim3(tiles), dim3(64), 0, stream, A, X, S, O);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Instanced scenes (rt_instanced.h): per-instance MeshArgs in a device array, a hierarchy over
+// the instances' world boxes.  Two per-lane stacks in LDS: one for the walk over the hierarchy,
+// one for the walk inside an instance's BVH.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) render_instanced(const FrameArgs A, const InstancedArgs I, const SceneArgs S, const OutputPlanes O,
+                                                          int32_t* __restrict__ hit_tri) {
+    __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
+    __shared__ uint32_t lds_tstack[kTlasStackDepth * BLOCK];
+    LdsStack<BLOCK> stack, tstack;
+    stack.init(&lds_stack[threadIdx.x]);
+    tstack.init(&lds_tstack[threadIdx.x]);
+    GlobalNodes nodes; nodes.all = S.pairs;
+    const int tiles_x = (A.width + 7) >> 3;
+    const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    int px, py;
+    tile_pixel(tile, threadIdx.x & 63, tiles_x, px, py);
+    LaneTotals tot = {0, 0, 0, 0, 0};
+    if (px < A.width && py < A.height) {
+        Work work; work.slabs = 0; work.tris = 0;
+        const InstancedOut r = shade_instanced_pixel<COUNT>(A, I, nodes, Solo(), px, py, stack, tstack, work);
+        const size_t p = (size_t)py * (size_t)A.width + (size_t)px;
+        uint8_t* rgb = O.rgb + p * 3;
+        rgb[0] = r.r; rgb[1] = r.g; rgb[2] = r.b;
+        if (O.hit_id) O.hit_id[p] = r.inst;
+        if (hit_tri) hit_tri[p] = r.tri;
+        if (O.hit_t) O.hit_t[p] = r.hit_t;
+        if (O.shadow) O.shadow[p] = r.shadow;
+        tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
+    }
+    if (COUNT) flush_counters(O.counters, tot);
+}
+
+hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const SceneArgs& S, const OutputPlanes& O, int32_t* hit_tri,
+                            int block, hipStream_t stream) {
+    if (A.width <= 0 || A.height <= 0 || !O.rgb || I.n_inst < 0 || (I.n_inst > 0 && (!I.inst || !I.order))) return hipErrorInvalidValue;
+    const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
+    if (count && !O.counters) return hipErrorInvalidValue;
+    const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
+    if (block == 256) {
+        const int blocks = (tiles + 3) / 4;
+        if (count) hipLaunchKernelGGL((render_instanced<256, true>), dim3(blocks), dim3(256), 0, stream, A, I, S, O, hit_tri);
+        else       hipLaunchKernelGGL((render_instanced<256, false>), dim3(blocks), dim3(256), 0, stream, A, I, S, O, hit_tri);
+    } else {
+        if (count) hipLaunchKernelGGL((render_instanced<64, true>), dim3(tiles), dim3(64), 0, stream, A, I, S, O, hit_tri);
+        else       hipLaunchKernelGGL((render_instanced<64, false>), dim3(tiles), dim3(64), 0, stream, A, I, S, O, hit_tri);
     }
     return hipGetLastError();
 }

@@ -120,6 +120,21 @@ struct SampleArgs {
     float lit_inv[kMaxMeshes][kMaxLights][3];    // its reciprocal
 };
 
+// Instanced scenes: any number of placed meshes (the reference's Scene.meshes may hold the same
+// triangles under many transforms, scene.c:31-35).  Every instance has a full MeshArgs in a device
+// array, in the scene's mesh order; a two-level hierarchy over the instances' world-space boxes
+// (same PairNode records; a leaf lists entries of `order`) only decides which instances a ray needs
+// to be tested against -- the test itself is the reference's, in the instance's own space.
+constexpr int kTlasStackDepth = 32;
+struct InstancedArgs {
+    const MeshArgs* inst;        // n_inst records
+    int32_t n_inst;
+    uint32_t tlas_root;          // leaf ref or PairNode index 0 of `tlas`
+    const PairNode* tlas;
+    const uint32_t* order;       // instance indices, grouped by hierarchy leaf
+    float root_min[3], root_max[3];
+};
+
 struct DeviceCounters {          // accumulated with atomics when counting is requested
     unsigned long long primary_rays, shadow_rays, slab_tests, tri_tests, hit_pixels, shadowed_pixels;
 };

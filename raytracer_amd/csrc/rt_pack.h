@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -337,5 +338,92 @@ inline bool coop_rect(const WorldBox& b, const double scene_lo[3], const double 
     rect[2] = tile_hi(hi[0], tiles_x); rect[3] = tile_hi(hi[1], tiles_y);
     return true;
 }
+
+
+// ---- hierarchy over placed instances (never used for results, only to propose instances) ----------
+// World-space box of an instance, padded so that float rounding in the world-space slab test can never
+// reject a ray that the exact test in the instance's own space would accept: 1e-4 of the box's extent
+// plus 1e-4 absolute on every side, then rounded outwards to float.
+struct InstanceBox { float lo[3], hi[3]; };
+
+inline InstanceBox instance_box(const rt_transform& tf, const float* bmin, const float* bmax) {
+    const WorldBox w = world_box(tf, bmin, bmax);
+    InstanceBox b;
+    for (int i = 0; i < 3; i++) {
+        const double pad = 1e-4 * (w.hi[i] - w.lo[i]) + 1e-4 + 1e-6 * (fabs(w.lo[i]) + fabs(w.hi[i]));
+        b.lo[i] = nextafterf((float)(w.lo[i] - pad), -INFINITY);
+        b.hi[i] = nextafterf((float)(w.hi[i] + pad), INFINITY);
+    }
+    return b;
+}
+
+struct Tlas {
+    std::vector<PairNode> pairs;
+    std::vector<uint32_t> order;      // instance indices, leaf after leaf
+    uint32_t root_ref = kLeafBit;     // empty leaf
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    int depth = 0;
+};
+
+class TlasBuilder {
+public:
+    // boxes[k] belongs to instance ids[k]; median split of the centroids along their longest axis,
+    // leaves of at most two instances.
+    TlasBuilder(const std::vector<InstanceBox>& boxes, const std::vector<uint32_t>& ids, Tlas& out) : boxes_(boxes), ids_(ids), out_(out) {}
+
+    void run() {
+        out_ = Tlas();
+        std::vector<uint32_t> items(boxes_.size());
+        for (size_t i = 0; i < items.size(); i++) items[i] = (uint32_t)i;
+        if (items.empty()) return;
+        out_.order.reserve(items.size());
+        InstanceBox root;
+        out_.root_ref = emit(items.data(), items.size(), 0, root);
+        memcpy(out_.root_min, root.lo, 12); memcpy(out_.root_max, root.hi, 12);
+    }
+
+private:
+    uint32_t emit(uint32_t* items, size_t n, int depth, InstanceBox& box) {
+        for (int i = 0; i < 3; i++) { box.lo[i] = INFINITY; box.hi[i] = -INFINITY; }
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t k = 0; k < n; k++) {
+            const InstanceBox& b = boxes_[items[k]];
+            for (int i = 0; i < 3; i++) {
+                box.lo[i] = b.lo[i] < box.lo[i] ? b.lo[i] : box.lo[i];
+                box.hi[i] = b.hi[i] > box.hi[i] ? b.hi[i] : box.hi[i];
+                const float c = 0.5f * b.lo[i] + 0.5f * b.hi[i];
+                clo[i] = c < clo[i] ? c : clo[i]; chi[i] = c > chi[i] ? c : chi[i];
+            }
+        }
+        if (n <= 2) {
+            const uint32_t first = (uint32_t)out_.order.size();
+            for (size_t k = 0; k < n; k++) out_.order.push_back(ids_[items[k]]);
+            return leaf_ref(first, (uint32_t)n);
+        }
+        int axis = 0;
+        if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+        if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+        const size_t mid = n / 2;
+        std::nth_element(items, items + mid, items + n, [&](uint32_t a, uint32_t b) {
+            const float ca = boxes_[a].lo[axis] + boxes_[a].hi[axis], cb = boxes_[b].lo[axis] + boxes_[b].hi[axis];
+            return ca < cb || (ca == cb && a < b);
+        });
+        const uint32_t me = (uint32_t)out_.pairs.size();
+        out_.pairs.emplace_back();
+        if (depth + 1 > out_.depth) out_.depth = depth + 1;
+        InstanceBox lb, rb;
+        const uint32_t l = emit(items, mid, depth + 1, lb);
+        const uint32_t r = emit(items + mid, n - mid, depth + 1, rb);
+        PairNode& p = out_.pairs[me];
+        memcpy(p.lmin, lb.lo, 12); memcpy(p.lmax, lb.hi, 12);
+        memcpy(p.rmin, rb.lo, 12); memcpy(p.rmax, rb.hi, 12);
+        p.lref = l; p.rref = r; p.pad[0] = p.pad[1] = 0;
+        return me;
+    }
+
+    const std::vector<InstanceBox>& boxes_;
+    const std::vector<uint32_t>& ids_;
+    Tlas& out_;
+};
 
 }  // namespace rt

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Times the instanced stress configuration: the treasure mesh placed on a seeded grid (about ten
+million placed triangles), the ground and the moving drone, the instance hierarchy rebuilt for every
+frame (rt_render_frame_instanced).  Prints one JSON line.
+
+    python scripts/instanced_bench.py --side 56 --frames 0,45
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--side", type=int, default=56, help="treasures per side of the grid")
+    p.add_argument("--spacing", type=float, default=1.05)
+    p.add_argument("--frames", default="0,45")
+    p.add_argument("--reps", type=int, default=5)
+    a = p.parse_args()
+    from raytracer_amd import capi, demo
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    scene = demo.DemoScene(0)
+    ctx = scene.ctx
+    rng = np.random.default_rng(3)
+    ids, tfs = [0, 2], [None, capi.Transform()]
+    half = (a.side - 1) / 2.0
+    for gx in range(a.side):
+        for gz in range(a.side):
+            ids.append(1)
+            tfs.append(capi.Transform(capi.Vec3((gx - half) * a.spacing, 0.45 + 0.1 * rng.uniform(), (gz - half) * a.spacing),
+                                      capi.Vec3(0.1 * rng.uniform(), rng.uniform(0, 6.28), 0)))
+    tri_counts = [int(m.triangle_count) for m in scene.meshes]
+    placed = sum(tri_counts[i] for i in ids)
+    W, H = a.width, a.height
+    rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    rows = []
+    for f in [int(x) for x in a.frames.split(",")]:
+        tfs[0] = scene.transforms(f)[0]                              # the drone moves, everything else stays
+        inst = capi.Context.make_instances(ids, tfs)
+        ctx.render_instanced(scene.camera, scene.light, inst, W, H, rgb, flags=capi.RT_FLAG_COUNT_WORK)
+        ctx.sync()
+        c = ctx.last_counters()
+        ms, wall = [], []
+        for _ in range(a.reps):
+            t0 = time.perf_counter()
+            ctx.render_instanced(scene.camera, scene.light, inst, W, H, rgb)
+            ctx.sync()
+            wall.append((time.perf_counter() - t0) * 1e3)
+            ms.append(ctx.last_kernel_ms())
+        t = float(np.median(ms))
+        rays = c["primary_rays"] + c["shadow_rays"]
+        rows.append({"frame": f, "kernel_ms": round(t, 3), "call_ms_with_host_rebuild": round(float(np.median(wall)), 3),
+                     "rays": rays, "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1)})
+    out = {"metric": "Mrays/s (primary+shadow), instanced scene", "unit": "Mrays/s",
+           "value": round(float(np.mean([r["Mrays_per_s"] for r in rows])), 1),
+           "config": {"workload": f"{W}x{H}, {len(ids)} instances ({placed} placed triangles): {a.side}x{a.side} treasures + ground + drone, "
+                                  "hierarchy over the instances rebuilt on the host per frame"},
+           "dtype": "f32", "frames": rows}
+    print(json.dumps(out), flush=True)
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,8 @@ def lib():
         L.emul_sample_offset.restype = None
         L.emul_render_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, C.c_uint32,
                                           i32, i32, vp, vp, C.POINTER(Counters)]
+        L.emul_render_instanced.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), vp, vp, i32, i32, i32, vp, vp, vp, vp, vp,
+                                            C.POINTER(Counters), C.POINTER(i32), C.POINTER(i32)]
         L.emul_upscale.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         L.emul_upscale.restype = None
         _lib = L
@@ -137,6 +139,24 @@ class Scene:
                                        rgb.ctypes.data, hid.ctypes.data, C.byref(cnt))
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_id": hid, "counters": cnt.as_dict()}
+
+    def render_instanced(self, cam, light, mesh_ids, tfs, w, h):
+        ids = np.ascontiguousarray(mesh_ids, np.int32)
+        arr = (Transform * max(len(tfs), 1))(*[conv(t, Transform) for t in tfs])
+        rgb = np.zeros((h, w, 3), np.uint8)
+        inst = np.zeros((h, w), np.int32)
+        tri = np.zeros((h, w), np.int32)
+        ht = np.zeros((h, w), np.float32)
+        sh = np.zeros((h, w), np.uint8)
+        cnt = Counters()
+        pairs, depth = C.c_int32(0), C.c_int32(0)
+        cam2, light2 = conv(cam, Camera), conv(light, Light)
+        st = lib().emul_render_instanced(self.h, C.byref(cam2), C.byref(light2), ids.ctypes.data, arr, len(tfs), w, h,
+                                         rgb.ctypes.data, inst.ctypes.data, tri.ctypes.data, ht.ctypes.data, sh.ctypes.data,
+                                         C.byref(cnt), C.byref(pairs), C.byref(depth))
+        assert st == 0, self.error()
+        return {"rgb": rgb, "hit_inst": inst, "hit_tri": tri, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(),
+                "tlas_pairs": pairs.value, "tlas_depth": depth.value}
 
     def close(self):
         if self.h:

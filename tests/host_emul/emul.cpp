@@ -11,6 +11,7 @@
 #include "../../raytracer_amd/csrc/rt_bicubic.h"
 #include "../../raytracer_amd/csrc/rt_pack.h"
 #include "../../raytracer_amd/csrc/rt_pixel.h"
+#include "../../raytracer_amd/csrc/rt_instanced.h"
 #include "../../raytracer_amd/csrc/rt_sampled.h"
 
 using namespace rt;
@@ -177,6 +178,63 @@ int emul_render_sampled(void* sp, const rt_camera* cam, const rt_light* lights, 
     }
     if (counters) {
         counters->primary_rays = (uint64_t)width * height * (uint64_t)spp; counters->shadow_rays = c_hit * (uint64_t)n_lights;
+        counters->slab_tests = c_slab; counters->tri_tests = c_tri;
+        counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
+    }
+    return RT_OK;
+}
+
+// The product's instanced pixel (rt_instanced.h) with the product's instance hierarchy (rt_pack.h).
+int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light, const int32_t* mesh_ids, const rt_transform* tfs, int32_t n_inst,
+                          int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_inst, int32_t* hit_tri, float* hit_t, uint8_t* shadow,
+                          rt_counters* counters, int32_t* tlas_pairs, int32_t* tlas_depth) {
+    EmulScene* s = (EmulScene*)sp;
+    FrameArgs A; memset(&A, 0, sizeof A);
+    fill_camera(*cam, *light, width, height, A);
+    A.n_mesh = 0;
+    std::vector<uint32_t> base(s->meshes.size() + 1, 0);
+    for (size_t m = 0; m < s->meshes.size(); m++) base[m + 1] = base[m] + (uint32_t)s->meshes[m].pk.pairs.size();
+    std::vector<MeshArgs> inst((size_t)n_inst);
+    std::vector<InstanceBox> boxes;
+    std::vector<uint32_t> ids;
+    for (int32_t i = 0; i < n_inst; i++) {
+        if (mesh_ids[i] < 0 || mesh_ids[i] >= (int32_t)s->meshes.size()) { s->err = "mesh id"; return RT_ERR_INVALID; }
+        const EmulMesh& E = s->meshes[(size_t)mesh_ids[i]];
+        MeshArgs& M = inst[(size_t)i];
+        memset(&M, 0, sizeof M);
+        M.pair_base = base[(size_t)mesh_ids[i]]; M.pair_count = (uint32_t)E.pk.pairs.size();
+        M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
+        memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
+        M.root_ref = E.pk.root_ref; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        fill_placement(tfs[i], A, M);
+        if (!M.empty) { boxes.push_back(instance_box(tfs[i], M.root_min, M.root_max)); ids.push_back((uint32_t)i); }
+    }
+    Tlas T;
+    TlasBuilder(boxes, ids, T).run();
+    if (tlas_pairs) *tlas_pairs = (int32_t)T.pairs.size();
+    if (tlas_depth) *tlas_depth = T.depth;
+    InstancedArgs I;
+    I.inst = inst.data(); I.n_inst = (int32_t)ids.size(); I.tlas_root = T.root_ref; I.tlas = T.pairs.data(); I.order = T.order.data();
+    memcpy(I.root_min, T.root_min, 12); memcpy(I.root_max, T.root_max, 12);
+    GlobalNodes nodes; nodes.all = s->all_pairs.data();
+    unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
+    #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_slab, c_tri, c_hit, c_dark)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            ArrayStack st, ts;
+            Work w; w.slabs = 0; w.tris = 0;
+            const InstancedOut r = shade_instanced_pixel<true>(A, I, nodes, Solo(), x, y, st, ts, w);
+            const size_t p = (size_t)y * width + x;
+            rgb[p * 3] = r.r; rgb[p * 3 + 1] = r.g; rgb[p * 3 + 2] = r.b;
+            if (hit_inst) hit_inst[p] = r.inst;
+            if (hit_tri) hit_tri[p] = r.tri;
+            if (hit_t) hit_t[p] = r.hit_t;
+            if (shadow) shadow[p] = r.shadow;
+            c_slab += w.slabs; c_tri += w.tris; c_hit += r.hit; c_dark += r.dark;
+        }
+    }
+    if (counters) {
+        counters->primary_rays = (uint64_t)width * height; counters->shadow_rays = c_hit;
         counters->slab_tests = c_slab; counters->tri_tests = c_tri;
         counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
     }

@@ -1,0 +1,239 @@
+"""Scenes with many placed meshes.  The reference's Scene.meshes may hold the same geometry under any
+number of transforms (add_mesh_to_scene, scene.c:31-35) and render_scene tests every ray against every
+entry (scene.c:72-108, 124-139); the oracle does exactly that.  The product proposes instances through a
+hierarchy over their world boxes and must produce the same planes, bit for bit."""
+import numpy as np
+import pytest
+
+import emul
+from conftest import bits
+
+
+def grid_scene(po, n_side, seed, frame=10, spacing=1.1):
+    """drone, ground and an n_side x n_side grid of treasures with seeded heights and rotations.
+    Returns (mesh ids, transforms)."""
+    rng = np.random.default_rng(seed)
+    ids = [0, 2]
+    tfs = [po.animation_transforms(frame)[0], po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))]
+    half = (n_side - 1) / 2.0
+    for gx in range(n_side):
+        for gz in range(n_side):
+            ids.append(1)
+            tfs.append(po.Transform(po.vec3((gx - half) * spacing, 0.45 + 0.1 * rng.uniform(), (gz - half) * spacing),
+                                    po.vec3(0.1 * rng.uniform(), rng.uniform(0, 6.28), 0)))
+    return ids, tfs
+
+
+def oracle_planes(po, meshes, ids, tfs, cam, light, w, h):
+    fr = po.render_frame([meshes[i] for i in ids], tfs, cam, light, w, h)
+    assert len(ids) < 128                                   # the oracle packs (list index << 24) | triangle into one int32
+    inst = np.where(fr.hit_id >= 0, fr.hit_id >> 24, -1)
+    tri = np.where(fr.hit_id >= 0, fr.hit_id & 0xFFFFFF, -1)
+    return fr, inst, tri
+
+
+@pytest.fixture(scope="module")
+def em_default(meshes):
+    s = emul.Scene()
+    for m in meshes:
+        assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+    yield s
+    s.close()
+
+
+def check(got, fr, inst, tri):
+    assert np.array_equal(got["hit_inst"], inst), int((got["hit_inst"] != inst).sum())
+    assert np.array_equal(got["hit_tri"], tri)
+    assert np.array_equal(bits(got["hit_t"]), bits(fr.hit_t))
+    assert np.array_equal(got["shadow"], fr.shadow)
+    assert np.array_equal(got["rgb"], fr.rgb)
+
+
+# ------------------------------------------------------------------------------------------ CPU
+
+def test_three_instances_are_the_reference_scene(po, meshes, em_default, golden_frames):
+    """One instance per mesh in the driver's order = the driver's scene."""
+    for f in (0, 45, 95):
+        got = em_default.render_instanced(po.default_camera(), po.default_light(), [0, 1, 2], po.animation_transforms(f), 240, 135)
+        assert np.array_equal(got["rgb"], golden_frames[f"f{f}_rgb"])
+        want = golden_frames[f"f{f}_hit_id"]
+        assert np.array_equal(np.where(got["hit_inst"] >= 0, (got["hit_inst"] << 24) | got["hit_tri"], -1), want)
+        assert np.array_equal(bits(got["hit_t"]), bits(golden_frames[f"f{f}_hit_t"]))
+        assert np.array_equal(got["shadow"], golden_frames[f"f{f}_shadow"])
+
+
+@pytest.mark.parametrize("n_side,size", [(1, (96, 54)), (5, (160, 90)), (10, (120, 68))])
+def test_grid_of_instances_equals_reference_loop(po, meshes, em_default, n_side, size):
+    ids, tfs = grid_scene(po, n_side, seed=n_side)
+    fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), *size)
+    got = em_default.render_instanced(po.default_camera(), po.default_light(), ids, tfs, *size)
+    check(got, fr, inst, tri)
+    assert got["counters"]["hit_pixels"] == fr.counters["hit_pixels"] and got["counters"]["shadowed_pixels"] == fr.counters["shadowed_pixels"]
+    # the hierarchy spares most of the reference's per-mesh work
+    if n_side >= 5:
+        assert got["counters"]["slab_tests"] < fr.counters["slab_tests"] // 2
+        assert (inst > 1).any() and (fr.shadow == 1).any()
+
+
+def test_coincident_instances_earlier_list_entry_wins(po, meshes, em_default):
+    """The same mesh twice at the same place: every hit distance ties; the reference keeps the earlier mesh (scene.c:82)."""
+    tf = po.Transform(po.vec3(0.3, 0.5, 0.2), po.vec3(0.1, 0.7, 0))
+    ground = po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))
+    for ids, tfs, later in (([1, 1, 2], [tf, tf, ground], {1}), ([2, 1, 2, 1], [ground, tf, ground, tf], {2, 3})):
+        fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), 120, 68)
+        got = em_default.render_instanced(po.default_camera(), po.default_light(), ids, tfs, 120, 68)
+        check(got, fr, inst, tri)
+        hit = set(np.unique(inst[inst >= 0]).tolist())
+        assert hit and not (hit & later)                       # never the later twin
+
+
+def test_single_leaf_meshes_and_empty_meshes_as_instances(po, meshes):
+    """Meshes whose BVH is one leaf use the caller's bound inside the leaf (bvh.c:85); empty meshes are never hit."""
+    from test_host_emul import tri_rows, checker
+    small = tri_rows([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]], [[-1, -1, 0.5], [1, -1, 0.5], [0, 1, 0.5]]])
+    post, nodes = po.build_bvh(small)
+    e_post, e_nodes = po.build_bvh(np.zeros((0, 24), np.float32))
+    s = emul.Scene()
+    parts = [(post, nodes, checker()), (e_post, e_nodes, checker()), (meshes[2].tris, meshes[2].nodes, meshes[2].rgba)]
+    host_meshes = []
+    for t, n, r in parts:
+        assert s.add(t, n, r) == 0
+        host_meshes.append(po.HostMesh(np.ascontiguousarray(t, np.float32), n, r))
+    ids = [0, 1, 0, 2, 0]
+    tfs = [po.Transform(po.vec3(0, 1, 0), po.vec3(0, 0.3, 0)), po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0)),
+           po.Transform(po.vec3(0.2, 1.1, 0.4), po.vec3(0.2, 0.3, 0)), po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0)),
+           po.Transform(po.vec3(0, 1, 0), po.vec3(0, 0.3, 0))]                      # the last one coincides with the first
+    fr, inst, tri = oracle_planes(po, host_meshes, ids, tfs, po.default_camera(), po.default_light(), 128, 72)
+    got = s.render_instanced(po.default_camera(), po.default_light(), ids, tfs, 128, 72)
+    check(got, fr, inst, tri)
+    assert 0 in inst and 2 in inst and 4 not in inst and 1 not in inst
+    s.close()
+
+
+def test_thousands_of_instances_against_the_reference_loop(po, meshes, em_default):
+    """3 138 list entries (about 9.9 million placed triangles) at 64x36: the reference's loop over all of them per ray
+    is slow but still feasible at this size.  Its packed id (mesh << 24 | triangle) wraps for mesh >= 128, so the
+    instance is compared modulo 256."""
+    ids, tfs = grid_scene(po, 56, seed=3, spacing=1.05)
+    assert len(ids) == 56 * 56 + 2
+    w, h = 64, 36
+    fr = po.render_frame([meshes[i] for i in ids], tfs, po.default_camera(), po.default_light(), w, h)
+    got = em_default.render_instanced(po.default_camera(), po.default_light(), ids, tfs, w, h)
+    assert np.array_equal(got["rgb"], fr.rgb)
+    assert np.array_equal(bits(got["hit_t"]), bits(fr.hit_t))
+    assert np.array_equal(got["shadow"], fr.shadow)
+    hit = fr.hit_t < 1e30
+    assert np.array_equal(got["hit_inst"] >= 0, hit)
+    assert np.array_equal(got["hit_tri"][hit], fr.hit_id[hit] & 0xFFFFFF)
+    assert np.array_equal(got["hit_inst"][hit] & 0xFF, (fr.hit_id[hit] >> 24) & 0xFF)
+    assert got["tlas_depth"] <= 14 and len(np.unique(got["hit_inst"])) > 50
+
+
+def test_no_instances_is_background(po, em_default):
+    got = em_default.render_instanced(po.default_camera(), po.default_light(), [], [], 16, 9)
+    assert (got["rgb"] == 50).all() and (got["hit_inst"] == -1).all() and (got["shadow"] == 255).all()
+
+
+# ------------------------------------------------------------------------------------------ GPU
+
+@pytest.fixture(scope="module")
+def gscene(meshes):
+    from raytracer_amd import capi
+    c = capi.Context(0)
+    for m in meshes:
+        c.upload_mesh(m.tris, m.nodes, m.rgba)
+    yield c
+    c.close()
+
+
+def gpu_render(gscene, po, ids, tfs, w, h, flags=0, block=64):
+    import torch
+    from raytracer_amd import capi
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    l = po.default_light()
+    light = capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
+    inst = capi.Context.make_instances(ids, [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in tfs])
+    dev = "cuda:0"
+    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    hi = torch.empty((h, w), dtype=torch.int32, device=dev)
+    ht = torch.empty((h, w), dtype=torch.int32, device=dev)
+    t = torch.empty((h, w), dtype=torch.float32, device=dev)
+    sh = torch.empty((h, w), dtype=torch.uint8, device=dev)
+    gscene.set_option("block", block)
+    gscene.render_instanced(cam, light, inst, w, h, rgb, hit_instance=hi, hit_tri=ht, hit_t=t, shadow=sh, flags=flags)
+    gscene.sync()
+    gscene.set_option("block", 64)
+    return {"rgb": rgb.cpu().numpy(), "hit_inst": hi.cpu().numpy(), "hit_tri": ht.cpu().numpy(), "hit_t": t.cpu().numpy(),
+            "shadow": sh.cpu().numpy()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_side,size,block", [(1, (240, 135), 64), (5, (333, 211), 256), (10, (160, 90), 64)])
+def test_gpu_grid_equals_reference_loop(gscene, po, meshes, n_side, size, block):
+    from raytracer_amd import capi
+    ids, tfs = grid_scene(po, n_side, seed=n_side)
+    fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), *size)
+    got = gpu_render(gscene, po, ids, tfs, *size, flags=capi.RT_FLAG_COUNT_WORK, block=block)
+    check(got, fr, inst, tri)
+    c = gscene.last_counters()
+    assert c["primary_rays"] == size[0] * size[1] and c["hit_pixels"] == fr.counters["hit_pixels"]
+    assert c["shadowed_pixels"] == fr.counters["shadowed_pixels"]
+
+
+@pytest.mark.gpu
+def test_gpu_three_instances_are_the_reference_scene(gscene, po, golden_hashes):
+    import hashlib
+    for f in (0, 45):
+        got = gpu_render(gscene, po, [0, 1, 2], po.animation_transforms(f), 1920, 1080)
+        want = golden_hashes["frames"][f"1920x1080_f{f}"]
+        assert hashlib.sha256(got["rgb"].tobytes()).hexdigest() == want["rgb"]
+        assert hashlib.sha256(got["hit_t"].tobytes()).hexdigest() == want["hit_t"]
+        assert hashlib.sha256(got["shadow"].tobytes()).hexdigest() == want["shadow"]
+        hid = np.where(got["hit_inst"] >= 0, (got["hit_inst"] << 24) | got["hit_tri"], -1).astype(np.int32)
+        assert hashlib.sha256(hid.tobytes()).hexdigest() == want["hit_id"]
+
+
+@pytest.mark.gpu
+def test_gpu_large_instance_list_against_cpu_pipeline(gscene, po, meshes, em_default):
+    """3 138 instances (about 9.9 million placed triangles): too slow for the reference's per-mesh loop at any useful
+    size, so a tile is checked against the oracle and the whole frame against the host build of the same pixel code."""
+    ids, tfs = grid_scene(po, 56, seed=3, spacing=1.05)
+    assert len(ids) == 56 * 56 + 2
+    w, h = 320, 180
+    got = gpu_render(gscene, po, ids, tfs, w, h)
+    ref = em_default.render_instanced(po.default_camera(), po.default_light(), ids, tfs, w, h)
+    for k in ("hit_inst", "hit_tri", "shadow", "rgb"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.array_equal(bits(got["hit_t"]), bits(ref["hit_t"]))
+    assert len(np.unique(got["hit_inst"])) > 200
+    # and a small frame of the same scene straight against the reference's loop over all 3 138 meshes
+    w, h = 96, 54
+    fr = po.render_frame([meshes[i] for i in ids], tfs, po.default_camera(), po.default_light(), w, h)
+    got = gpu_render(gscene, po, ids, tfs, w, h)
+    assert np.array_equal(got["rgb"], fr.rgb) and np.array_equal(got["shadow"], fr.shadow)
+    assert np.array_equal(bits(got["hit_t"]), bits(fr.hit_t))
+    hit = fr.hit_t < 1e30
+    assert np.array_equal(got["hit_tri"][hit], fr.hit_id[hit] & 0xFFFFFF)
+    assert np.array_equal(got["hit_inst"][hit] & 0xFF, (fr.hit_id[hit] >> 24) & 0xFF)
+
+
+@pytest.mark.gpu
+def test_gpu_instanced_argument_errors(gscene, po):
+    import torch
+    from raytracer_amd import capi
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    light = capi.Light(capi.Vec3(0, 1, 0), capi.Vec3(1, 1, 1))
+    rgb = torch.empty((8, 8, 3), dtype=torch.uint8, device="cuda:0")
+    bad = capi.Context.make_instances([7], [capi.Transform()])
+    with pytest.raises(capi.RtError):
+        gscene.render_instanced(cam, light, bad, 8, 8, rgb)
+    ok = capi.Context.make_instances([0], [capi.Transform()])
+    with pytest.raises(capi.RtError):
+        gscene.render_instanced(cam, light, ok, 8, 8, rgb, flags=capi.RT_FLAG_REFERENCE_ORDER)
+    with pytest.raises(capi.RtError):
+        gscene.render_instanced(cam, light, ok, 0, 8, rgb)
+    # an empty list renders the background
+    none = capi.Context.make_instances([], [])
+    gscene.render_instanced(cam, light, none, 8, 8, rgb)
+    gscene.sync()
+    assert (rgb.cpu().numpy() == 50).all()
