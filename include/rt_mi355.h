@@ -32,7 +32,9 @@ typedef enum {
 } rt_status;
 
 /* Limits of this build. */
-#define RT_MAX_MESHES        8          /* meshes per scene (one BVH each, reference scene.c:72) */
+#define RT_MAX_MESHES        8          /* meshes per scene (one BVH each, reference scene.c:72) in rt_render_frame,
+                                           rt_render_frames and rt_render_frame_sampled */
+#define RT_MAX_GEOMETRIES    256        /* meshes that can be uploaded (rt_render_frame_instanced places them) */
 #define RT_MAX_TREE_DEPTH    30         /* deepest BVH the traversal stack covers */
 #define RT_MAX_MESH_TRIS     (1 << 24)  /* triangles per mesh */
 #define RT_MAX_BATCH         16         /* frames per rt_render_frames call */
@@ -164,14 +166,19 @@ int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light
  * A hierarchy over the instances' world-space boxes, rebuilt on the host for every call, proposes the
  * instances a ray is tested against.  d_hit_instance (optional) receives the list index of the hit
  * (-1 = miss), d_hit_tri (optional) the triangle index inside its mesh, d_hit_t / d_shadow as in
- * rt_render_frame.  Not limited by RT_MAX_MESHES: n_instances <= RT_MAX_INSTANCES; the uploaded
- * meshes themselves are still at most RT_MAX_MESHES. */
+ * rt_render_frame.  Not limited by RT_MAX_MESHES: n_instances <= RT_MAX_INSTANCES over at most
+ * RT_MAX_GEOMETRIES uploaded meshes. */
 typedef struct { int32_t mesh; rt_transform transform; } rt_instance;
 int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
                               const rt_instance* instances, int32_t n_instances,
                               int32_t width, int32_t height, uint32_t flags,
                               void* d_rgb, void* d_hit_instance, void* d_hit_tri, void* d_hit_t, void* d_shadow,
                               void* stream);
+
+/* The instanced frame into a host buffer (renders into context-owned device memory, waits, copies back). */
+int rt_render_frame_instanced_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
+                                   const rt_instance* instances, int32_t n_instances,
+                                   int32_t width, int32_t height, uint32_t flags, uint8_t* h_rgb);
 
 /* Same, for callers that hold host buffers (what scene->frames[current_frame] is in the
  * reference): renders into context-owned device planes, waits, and copies back. */

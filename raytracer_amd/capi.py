@@ -62,7 +62,7 @@ EXPORTS = [
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
-    "rt_render_frame_sampled", "rt_render_frame_instanced",
+    "rt_render_frame_sampled", "rt_render_frame_instanced", "rt_render_frame_instanced_host",
 ]
 
 _lib = None
@@ -115,6 +115,7 @@ def lib():
                                               u32, u32, vp, vp, vp]
         L.rt_render_frame_instanced.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Instance), i32, i32, i32, u32,
                                                 vp, vp, vp, vp, vp, vp]
+        L.rt_render_frame_instanced_host.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Instance), i32, i32, i32, u32, vp]
         L.rt_scaled_size.argtypes = [i32, i32, C.c_float, C.POINTER(i32), C.POINTER(i32)]
         L.rt_upscale_frames.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
         L.rt_upscale_frame_host.argtypes = [vp, vp, i32, i32, i32, i32, vp]

@@ -337,7 +337,7 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const r
     if (!ctx) return RT_ERR_INVALID;
     if (!h_rgba || tex_width <= 0 || tex_height <= 0) return fail(ctx, RT_ERR_INVALID, "texture missing or empty");
     if ((int64_t)tex_width * tex_height > (int64_t)1 << 28) return fail(ctx, RT_ERR_UNSUPPORTED, "texture too large");
-    if ((int)ctx->meshes.size() >= kMaxMeshes) return fail(ctx, RT_ERR_UNSUPPORTED, "too many meshes in one scene");
+    if ((int)ctx->meshes.size() >= RT_MAX_GEOMETRIES) return fail(ctx, RT_ERR_UNSUPPORTED, "too many meshes uploaded");
     PackedMesh pk;
     std::string why;
     int st = Packer(tris, n_tris, nodes, n_nodes, pk).run(why);
@@ -397,6 +397,7 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
     if (!ctx) return RT_ERR_INVALID;
     if (!camera || !light || !d_rgb) return fail(ctx, RT_ERR_INVALID, "camera, light and d_rgb are required");
     if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    if (ctx->meshes.size() > (size_t)kMaxMeshes) return fail(ctx, RT_ERR_UNSUPPORTED, "more than RT_MAX_MESHES meshes: use rt_render_frame_instanced");
     if (n_transforms != (int32_t)ctx->meshes.size() || (n_transforms > 0 && !transforms))
         return fail(ctx, RT_ERR_INVALID, "one transform per uploaded mesh is required");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -480,6 +481,7 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light
     if (n_frames < 1 || n_frames > RT_MAX_BATCH) return fail(ctx, RT_ERR_INVALID, "n_frames must be 1..RT_MAX_BATCH");
     if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
     if (frame_stride < (size_t)width * (size_t)height * 3) return fail(ctx, RT_ERR_INVALID, "frame_stride smaller than one image");
+    if (ctx->meshes.size() > (size_t)kMaxMeshes) return fail(ctx, RT_ERR_UNSUPPORTED, "more than RT_MAX_MESHES meshes: use rt_render_frame_instanced");
     if (n_transforms != (int32_t)ctx->meshes.size() || (n_transforms > 0 && !transforms))
         return fail(ctx, RT_ERR_INVALID, "one transform per uploaded mesh and frame is required");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -522,6 +524,7 @@ int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light
     if (samples_per_pixel < 1 || samples_per_pixel > RT_MAX_SAMPLES) return fail(ctx, RT_ERR_UNSUPPORTED, "samples_per_pixel must be 1..RT_MAX_SAMPLES");
     if (flags & RT_FLAG_REFERENCE_ORDER) return fail(ctx, RT_ERR_UNSUPPORTED, "RT_FLAG_REFERENCE_ORDER is not available for sampled frames");
     if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    if (ctx->meshes.size() > (size_t)kMaxMeshes) return fail(ctx, RT_ERR_UNSUPPORTED, "more than RT_MAX_MESHES meshes: use rt_render_frame_instanced");
     if (n_transforms != (int32_t)ctx->meshes.size() || (n_transforms > 0 && !transforms))
         return fail(ctx, RT_ERR_INVALID, "one transform per uploaded mesh is required");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -639,6 +642,23 @@ int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* l
     if (h_hit_id) RT_HIP(ctx, hipMemcpy(h_hit_id, ctx->d_id, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (h_hit_t) RT_HIP(ctx, hipMemcpy(h_hit_t, ctx->d_t, pixels * sizeof(float), hipMemcpyDeviceToHost));
     if (h_shadow) RT_HIP(ctx, hipMemcpy(h_shadow, ctx->d_shadow, pixels, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_render_frame_instanced_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_instance* instances,
+                                   int32_t n_instances, int32_t width, int32_t height, uint32_t flags, uint8_t* h_rgb) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!h_rgb) return fail(ctx, RT_ERR_INVALID, "h_rgb is required");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t pixels = (size_t)width * (size_t)height;
+    int st = ensure_planes(ctx, pixels);
+    if (st != RT_OK) return st;
+    st = rt_render_frame_instanced(ctx, camera, light, instances, n_instances, width, height, flags, ctx->d_rgb, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr);
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(h_rgb, ctx->d_rgb, pixels * 3, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

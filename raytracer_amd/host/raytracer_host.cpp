@@ -36,7 +36,7 @@ struct MeshKey {
 };
 struct SceneState {
     rt_ctx* ctx = nullptr;
-    std::vector<MeshKey> uploaded;
+    std::vector<MeshKey> geometries;      // distinct (triangles, BVH, texture) uploaded, in upload order
     int last_status = 0;
 };
 std::mutex g_lock;
@@ -56,39 +56,63 @@ SceneState* state_of(const Scene* scene, bool create) {
     return &g_states[(const void*)scene->frames];
 }
 
-int sync_scene(Scene* scene, SceneState& st) {
+// Brings the GPU's geometry list in line with the scene's meshes.  Scene.meshes may repeat a geometry
+// (the same triangle array, BVH and texture under another transform): each distinct one is uploaded once
+// and geometry_of[i] says which one mesh i uses.
+int sync_scene(Scene* scene, SceneState& st, std::vector<int32_t>& geometry_of) {
     if (!st.ctx) {
         int rc = rt_ctx_create(pick_device(), &st.ctx);
         if (rc != RT_OK) { fprintf(stderr, "render_scene: cannot open GPU %d: %s\n", pick_device(), rt_status_string(rc)); return rc; }
     }
     std::vector<MeshKey> now;
+    geometry_of.assign(scene->mesh_count, -1);
     for (size_t i = 0; i < scene->mesh_count; i++) {
         const Mesh& m = scene->meshes[i];
-        now.push_back(MeshKey{m.triangles, m.texture_data, m.bvh.root, m.triangle_count, m.texture_width, m.texture_height});
+        const MeshKey k{m.triangles, m.texture_data, m.bvh.root, m.triangle_count, m.texture_width, m.texture_height};
+        size_t g = 0;
+        while (g < now.size() && !(now[g] == k)) g++;
+        if (g == now.size()) now.push_back(k);
+        geometry_of[i] = (int32_t)g;
     }
-    if (now == st.uploaded) return RT_OK;
+    if (now == st.geometries) return RT_OK;
     int rc = rt_scene_clear(st.ctx);
-    st.uploaded.clear();
-    for (size_t i = 0; rc == RT_OK && i < scene->mesh_count; i++) {
-        const Mesh& m = scene->meshes[i];
-        if (!m.bvh.root || !m.texture_data) { fprintf(stderr, "render_scene: mesh %zu was not loaded\n", i); return RT_ERR_INVALID; }
-        rc = rt_mesh_upload_tree(st.ctx, (const rt_triangle*)m.triangles, (int32_t)m.triangle_count,
-                                 (const rt_tree_node*)m.bvh.root, m.texture_data, m.texture_width, m.texture_height, nullptr);
+    st.geometries.clear();
+    for (size_t g = 0; rc == RT_OK && g < now.size(); g++) {
+        const MeshKey& k = now[g];
+        if (!k.root || !k.tex) { fprintf(stderr, "render_scene: a mesh of the scene was not loaded\n"); return RT_ERR_INVALID; }
+        rc = rt_mesh_upload_tree(st.ctx, (const rt_triangle*)k.tris, (int32_t)k.n, (const rt_tree_node*)k.root, (const uint8_t*)k.tex, k.tw, k.th, nullptr);
     }
     if (rc != RT_OK) { fprintf(stderr, "render_scene: scene upload failed: %s (%s)\n", rt_status_string(rc), rt_last_error(st.ctx)); return rc; }
-    st.uploaded = now;
+    st.geometries = now;
     return RT_OK;
 }
 
 int render_into(Scene* scene, uint8_t* rgb, int32_t* hit_id, float* hit_t, uint8_t* shadow) {
     std::lock_guard<std::mutex> g(g_lock);
     SceneState* st = state_of(scene, true);
-    int rc = sync_scene(scene, *st);
+    std::vector<int32_t> geometry_of;
+    int rc = sync_scene(scene, *st, geometry_of);
     if (rc == RT_OK) {
-        std::vector<rt_transform> tfs(scene->mesh_count);
-        for (size_t i = 0; i < scene->mesh_count; i++) memcpy(&tfs[i], &scene->meshes[i].transform, sizeof(rt_transform));
-        rc = rt_render_frame_host(st->ctx, (const rt_camera*)&scene->camera, (const rt_light*)&scene->light, tfs.data(),
-                                  (int32_t)tfs.size(), scene->width, scene->height, 0, rgb, hit_id, hit_t, shadow);
+        // one mesh per geometry, in order, and few enough: the plain frame; otherwise the mesh list is a
+        // list of placed geometries
+        bool plain = scene->mesh_count == st->geometries.size() && scene->mesh_count <= (size_t)RT_MAX_MESHES;
+        if (plain) {
+            std::vector<rt_transform> tfs(scene->mesh_count);
+            for (size_t i = 0; i < scene->mesh_count; i++) memcpy(&tfs[i], &scene->meshes[i].transform, sizeof(rt_transform));
+            rc = rt_render_frame_host(st->ctx, (const rt_camera*)&scene->camera, (const rt_light*)&scene->light, tfs.data(),
+                                      (int32_t)tfs.size(), scene->width, scene->height, 0, rgb, hit_id, hit_t, shadow);
+        } else if (hit_id || hit_t || shadow) {
+            rc = RT_ERR_UNSUPPORTED;
+            fprintf(stderr, "render_scene: debug planes are not available for scenes with repeated or more than %d meshes\n", RT_MAX_MESHES);
+        } else {
+            std::vector<rt_instance> inst(scene->mesh_count);
+            for (size_t i = 0; i < scene->mesh_count; i++) {
+                inst[i].mesh = geometry_of[i];
+                memcpy(&inst[i].transform, &scene->meshes[i].transform, sizeof(rt_transform));
+            }
+            rc = rt_render_frame_instanced_host(st->ctx, (const rt_camera*)&scene->camera, (const rt_light*)&scene->light, inst.data(),
+                                                (int32_t)inst.size(), scene->width, scene->height, 0, rgb);
+        }
         if (rc != RT_OK) fprintf(stderr, "render_scene: %s (%s)\n", rt_status_string(rc), rt_last_error(st->ctx));
     }
     st->last_status = rc;

@@ -237,3 +237,39 @@ def test_gpu_instanced_argument_errors(gscene, po):
     gscene.render_instanced(cam, light, none, 8, 8, rgb)
     gscene.sync()
     assert (rgb.cpu().numpy() == 50).all()
+
+
+@pytest.mark.gpu
+def test_gpu_reference_api_scene_with_repeated_meshes(po, meshes):
+    """The reference's own calls: one create_mesh per geometry, add_mesh_to_scene many times with different
+    placements (scene.c:31-35), render_scene.  More list entries than RT_MAX_MESHES, geometries uploaded once."""
+    import ctypes as C
+    import os
+    from raytracer_amd import host_api as H
+    L = H.lib()
+    scene = L.create_scene(200, 120, 1000, 4, 1.0)
+    L.set_scene_camera(C.byref(scene), H.Vec3(-3, 3, -3), H.Vec3(0, 0, 0), H.Vec3(0, 1, 0), 60.0)
+    L.set_scene_light(C.byref(scene), H.Vec3(1, 1, -1), H.Vec3(1.4, 1.4, 1.4))
+    loaded = [L.create_mesh(os.path.join(H.ASSETS, n + ".obj").encode(), os.path.join(H.ASSETS, n + ".webp").encode())
+              for n in ("drone", "treasure", "ground")]
+    ids, tfs = grid_scene(po, 4, seed=9)
+    for i, t in zip(ids, tfs):
+        m = loaded[i]
+        L.set_mesh_position(C.byref(m), H.Vec3(*t.position.tup()))
+        L.set_mesh_rotation(C.byref(m), H.Vec3(*t.rotation.tup()))
+        L.add_mesh_to_scene(C.byref(scene), m)
+    assert scene.mesh_count == 18
+    L.render_scene(C.byref(scene))
+    assert L.rt_host_last_status(C.byref(scene)) == 0
+    want = po.render_frame([meshes[i] for i in ids], tfs, po.default_camera(), po.default_light(), 200, 120, debug=False)
+    assert np.array_equal(H.frame_array(scene, 0), want.rgb)
+    # moving one entry and rendering the next frame re-uses the uploaded geometries
+    L.next_frame(C.byref(scene))
+    L.set_mesh_position(C.byref(scene.meshes[5]), H.Vec3(0.3, 1.2, -0.4))
+    tfs[5] = po.Transform(po.vec3(0.3, 1.2, -0.4), tfs[5].rotation)
+    L.render_scene(C.byref(scene))
+    want = po.render_frame([meshes[i] for i in ids], tfs, po.default_camera(), po.default_light(), 200, 120, debug=False)
+    assert np.array_equal(H.frame_array(scene, 1), want.rgb)
+    for m in loaded:
+        L.destroy_mesh(C.byref(m))
+    L.destroy_scene(C.byref(scene))
