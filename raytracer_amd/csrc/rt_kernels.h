@@ -8,7 +8,7 @@
 namespace rt {
 
 constexpr int kNumVariants = 10;     // kernel variants selectable through LaunchConfig::variant
-constexpr int kDefaultVariant = 0;
+constexpr int kDefaultVariant = 3;
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 
 struct LaunchConfig {
