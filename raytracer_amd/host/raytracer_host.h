@@ -84,6 +84,40 @@ void destroy_bvh(BVH* bvh);
 Camera create_camera(Vec3 position, Vec3 look_at, Vec3 up, float fov);
 DirectionalLight create_directional_light(Vec3 direction, Vec3 color);
 
+/* Value-type helpers of math/vec3.h:10-18, math/mat4.h:11-20, math/ray.h:18-21, geometry/aabb.h:15-18,
+ * render/camera.h:16 and utils/image.h:7-9, with the reference's float results.  Host utilities only:
+ * the frame path does not use them (intersect_bvh, the reference's CPU traversal, is not provided). */
+Vec3 vec3_add(Vec3 a, Vec3 b);
+Vec3 vec3_sub(Vec3 a, Vec3 b);
+Vec3 vec3_mul(Vec3 a, float t);
+Vec3 vec3_div(Vec3 a, float t);
+float vec3_dot(Vec3 a, Vec3 b);
+Vec3 vec3_cross(Vec3 a, Vec3 b);
+float vec3_length(Vec3 v);
+Vec3 vec3_normalize(Vec3 v);
+Vec3 vec3_mul_vec3(Vec3 a, Vec3 b);
+Mat4 mat4_identity(void);
+Mat4 mat4_multiply(Mat4 a, Mat4 b);
+Mat4 mat4_translation(Vec3 t);
+Mat4 mat4_rotation_x(float angle);
+Mat4 mat4_rotation_y(float angle);
+Mat4 mat4_rotation_z(float angle);
+Vec3 mat4_transform_point(Mat4 m, Vec3 p);
+Vec3 mat4_transform_vector(Mat4 m, Vec3 v);
+Mat4 mat4_inverse(Mat4 m);
+Mat4 mat4_transpose(Mat4 m);
+Ray transform_ray(Ray ray, Transform transform);
+Vec3 transform_normal(Vec3 normal, Transform transform);
+bool ray_triangle_intersect(Ray ray, Vec3 v0, Vec3 v1, Vec3 v2, float* t, float* u_out, float* v_out);
+AABB create_empty_aabb(void);
+AABB expand_aabb(AABB box, Vec3 point);
+AABB get_triangle_bounds(Triangle tri);
+bool ray_aabb_intersect(Ray ray, AABB box);
+Ray get_camera_ray(const Camera* camera, float x, float y, float aspect);
+float cubic_hermite(float A, float B, float C, float D, float t);
+uint32_t get_pixel_rgb(unsigned char* frame, int x, int y, int width, int height);
+uint32_t bicubic_interpolate(unsigned char* frame, float x, float y, int width, int height);
+
 /* ---- additions that the reference does not have ---- */
 /* GPU used by scenes created afterwards on this thread's process (default 0, or $RT_DEVICE). */
 void rt_host_set_device(int device);

@@ -65,6 +65,14 @@ class DirectionalLight(C.Structure):
     _fields_ = [("direction", Vec3), ("color", Vec3)]
 
 
+class Ray(C.Structure):
+    _fields_ = [("origin", Vec3), ("direction", Vec3)]
+
+
+class Mat4(C.Structure):
+    _fields_ = [("m", (C.c_float * 4) * 4)]
+
+
 class Scene(C.Structure):
     _fields_ = [("meshes", C.POINTER(Mesh)), ("mesh_count", C.c_size_t), ("camera", Camera), ("light", DirectionalLight),
                 ("frames", C.POINTER(C.POINTER(C.c_ubyte))), ("frame_count", C.c_int), ("current_frame", C.c_int),
@@ -140,6 +148,23 @@ def lib():
         L.rt_host_set_obj_mode.argtypes = [C.c_int]
         L.rt_host_scaled_size.argtypes = [C.POINTER(Scene), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rt_host_upscale_frame.argtypes = [C.POINTER(Scene), C.c_int, C.c_void_p]
+        # value-type helpers of the reference's math / aabb / camera / image headers
+        v3, f = Vec3, C.c_float
+        for name, res, args in (
+                ("vec3_add", v3, [v3, v3]), ("vec3_sub", v3, [v3, v3]), ("vec3_mul", v3, [v3, f]), ("vec3_div", v3, [v3, f]),
+                ("vec3_dot", f, [v3, v3]), ("vec3_cross", v3, [v3, v3]), ("vec3_length", f, [v3]), ("vec3_normalize", v3, [v3]),
+                ("vec3_mul_vec3", v3, [v3, v3]), ("mat4_identity", Mat4, []), ("mat4_multiply", Mat4, [Mat4, Mat4]),
+                ("mat4_translation", Mat4, [v3]), ("mat4_rotation_x", Mat4, [f]), ("mat4_rotation_y", Mat4, [f]),
+                ("mat4_rotation_z", Mat4, [f]), ("mat4_transform_point", v3, [Mat4, v3]), ("mat4_transform_vector", v3, [Mat4, v3]),
+                ("mat4_inverse", Mat4, [Mat4]), ("mat4_transpose", Mat4, [Mat4]), ("transform_ray", Ray, [Ray, Transform]),
+                ("transform_normal", v3, [v3, Transform]),
+                ("ray_triangle_intersect", C.c_bool, [Ray, v3, v3, v3, C.POINTER(f), C.POINTER(f), C.POINTER(f)]),
+                ("create_empty_aabb", AABB, []), ("expand_aabb", AABB, [AABB, v3]), ("get_triangle_bounds", AABB, [Triangle]),
+                ("ray_aabb_intersect", C.c_bool, [Ray, AABB]), ("get_camera_ray", Ray, [C.POINTER(Camera), f, f, f]),
+                ("cubic_hermite", f, [f, f, f, f, f]), ("get_pixel_rgb", C.c_uint32, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+                ("bicubic_interpolate", C.c_uint32, [C.c_void_p, f, f, C.c_int, C.c_int])):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
         for name in EXPORTS:
             getattr(L, name)
         _lib = L

@@ -289,3 +289,73 @@ def test_obj_reader_modes_agree_on_reference_assets(host, golden_hashes):
             H.destroy_mesh(C.byref(m))
     finally:
         H.rt_host_set_obj_mode(0)
+
+
+def test_value_type_helpers_equal_reference_vectors(host, golden_kat, golden_frames):
+    """The small functions of math/ray.h, geometry/aabb.h, render/camera.h and utils/image.h in the host library
+    against the known-answer vectors taken from the compiled reference."""
+    H = host.lib()
+    g = golden_kat
+    v3 = lambda a: host.Vec3(float(a[0]), float(a[1]), float(a[2]))          # noqa: E731
+    n = 1024
+    # ray_aabb_intersect (aabb.c:28-56)
+    got = np.array([H.ray_aabb_intersect(host.Ray(v3(g["aabb_o"][k]), v3(g["aabb_d"][k])), host.AABB(v3(g["aabb_lo"][k]), v3(g["aabb_hi"][k])))
+                    for k in range(g["aabb_hit"].shape[0])], np.int32)
+    assert np.array_equal(got, g["aabb_hit"])
+    # ray_triangle_intersect (ray.c:42-67)
+    hit = np.zeros(g["tri_hit"].shape[0], np.int32)
+    tuv = np.zeros((hit.size, 3), np.float32)
+    for k in range(hit.size):
+        t, u, v = C.c_float(0), C.c_float(0), C.c_float(0)
+        hit[k] = H.ray_triangle_intersect(host.Ray(v3(g["tri_o"][k]), v3(g["tri_d"][k])), v3(g["tri_v"][k, 0]), v3(g["tri_v"][k, 1]),
+                                          v3(g["tri_v"][k, 2]), C.byref(t), C.byref(u), C.byref(v))
+        if hit[k]:
+            tuv[k] = (t.value, u.value, v.value)
+    assert np.array_equal(hit, g["tri_hit"]) and np.array_equal(bits(tuv), bits(g["tri_tuv"]))
+    # transform_ray / transform_normal (ray.c:3-40)
+    rays, nrm = np.zeros((n, 6), np.float32), np.zeros((n, 3), np.float32)
+    for k in range(n):
+        tf = host.Transform(v3(g["tf_pos"][k]), v3(g["tf_rot"][k]))
+        r = H.transform_ray(host.Ray(v3(g["tf_o"][k]), v3(g["tf_d"][k])), tf)
+        rays[k] = (r.origin.x, r.origin.y, r.origin.z, r.direction.x, r.direction.y, r.direction.z)
+        m = H.transform_normal(v3(g["tf_d"][k]), tf)
+        nrm[k] = (m.x, m.y, m.z)
+    assert np.array_equal(bits(rays), bits(g["tf_ray"])) and np.array_equal(bits(nrm), bits(g["tf_normal"]))
+    # get_camera_ray (camera.c:12-30)
+    out = np.zeros((n, 6), np.float32)
+    for k in range(n):
+        p = g["cam_params"][k]
+        cam = host.Camera(v3(p[0:3]), v3(p[3:6]), v3(p[6:9]), float(p[9]))
+        r = H.get_camera_ray(C.byref(cam), float(g["cam_xy"][k, 0]), float(g["cam_xy"][k, 1]), float(g["cam_aspect"][k]))
+        out[k] = (r.origin.x, r.origin.y, r.origin.z, r.direction.x, r.direction.y, r.direction.z)
+    assert np.array_equal(bits(out), bits(g["cam_ray"]))
+    # bicubic_interpolate (image.c:25-78)
+    frame = np.ascontiguousarray(golden_frames["f0_rgb"])
+    got = np.array([H.bicubic_interpolate(frame.ctypes.data, float(g["bic_x"][k]), float(g["bic_y"][k]), 240, 135)
+                    for k in range(g["bic_x"].shape[0])], np.uint32)
+    assert np.array_equal(got, g["bic_out"])
+    assert H.get_pixel_rgb(frame.ctypes.data, -5, 999, 240, 135) == (int(frame[134, 0, 0]) << 16 | int(frame[134, 0, 1]) << 8 | int(frame[134, 0, 2]))
+
+
+def test_vec3_mat4_aabb_helpers(host):
+    H = host.lib()
+    a, b = host.Vec3(1, 2, 3), host.Vec3(-2, 0.5, 4)
+    c = H.vec3_cross(a, b)
+    assert (c.x, c.y, c.z) == (2 * 4 - 3 * 0.5, 3 * -2 - 1 * 4, 1 * 0.5 - 2 * -2)
+    assert H.vec3_dot(a, b) == np.float32(1 * -2 + 2 * 0.5 + 3 * 4)
+    nrm = H.vec3_normalize(a)
+    inv_len = np.float32(1) / np.sqrt(np.float32(14))
+    assert (nrm.x, nrm.y, nrm.z) == (np.float32(1) * inv_len, np.float32(2) * inv_len, np.float32(3) * inv_len)   # a * (1/len), vec3.c:15,35
+    m = H.mat4_multiply(H.mat4_translation(host.Vec3(1, 2, 3)), H.mat4_rotation_y(0.7))
+    back = H.mat4_multiply(m, H.mat4_inverse(m))
+    assert np.allclose(np.array([[back.m[i][j] for j in range(4)] for i in range(4)]), np.eye(4), atol=1e-6)
+    p = H.mat4_transform_point(m, host.Vec3(0, 0, 0))
+    assert (p.x, p.y, p.z) == (1, 2, 3)
+    t = H.mat4_transpose(m)
+    assert t.m[3][0] == m.m[0][3] == 1
+    e = H.create_empty_aabb()
+    assert e.min.x == np.float32(1e30) and e.max.z == np.float32(-1e30)
+    tri = host.Triangle(host.Vec3(0, 0, 0), host.Vec3(1, -1, 2), host.Vec3(-3, 4, 1))
+    bb = H.get_triangle_bounds(tri)
+    assert (bb.min.x, bb.min.y, bb.min.z, bb.max.x, bb.max.y, bb.max.z) == (-3, -1, 0, 1, 4, 2)
+    assert H.cubic_hermite(1, 2, 3, 4, 0.0) == 2 and H.cubic_hermite(1, 2, 3, 4, 1.0) == 3
