@@ -173,6 +173,8 @@ bool read_corner(const char*& p, long idx[3], size_t n_pos, size_t n_uv, size_t 
     return true;
 }
 
+float g_save_quality = 75.0f;   // WebPConfigInit's default (scene.c:174)
+int g_save_threads = 0;
 int g_obj_mode = 0;      // 0: the reference's reader; 1: tolerant reader (rt_host_set_obj_mode)
 
 }  // namespace
@@ -376,10 +378,28 @@ void render_scene(Scene* scene) {                                               
 }
 
 void save_scene(Scene* scene, const char* filename) {                                           // scene.c:162-225
-    // The reference assembles an animated WebP with libwebpmux, which this image does not ship.
-    // Like the reference when it cannot open its output file, report nothing to the caller.
-    (void)scene;
-    fprintf(stderr, "save_scene: animated WebP encoding is not available in this build; %s not written\n", filename ? filename : "(null)");
+    // Upscale on the GPU (scene.c:188-202), encode on host threads while the next frame is upscaled,
+    // frame times as the reference gives them to its encoder (scene.c:204, 209).  No status is
+    // returned, like the reference; problems are reported on stderr.
+    if (!scene || !filename || !scene->frames || scene->frame_count <= 0) return;
+    int sw = 0, sh = 0;
+    if (rt_host_scaled_size(scene, &sw, &sh) != RT_OK) { fprintf(stderr, "save_scene: bad scene size\n"); return; }
+    rt_host_animation* anim = nullptr;
+    if (rt_host_animation_open(filename, sw, sh, g_save_quality, g_save_threads, &anim) != RT_OK) {
+        fprintf(stderr, "save_scene: cannot write %s\n", filename);
+        return;
+    }
+    std::vector<uint32_t> argb((size_t)sw * (size_t)sh);
+    const int step = scene->duration_ms / scene->frame_count;
+    int rc = RT_OK;
+    for (int frame = 0; frame < scene->frame_count && rc == RT_OK; frame++) {
+        rc = rt_host_upscale_frame(scene, frame, argb.data());
+        // the encoder shows a frame from its timestamp to the next one's; the last one ends at duration_ms
+        const int shown = frame + 1 < scene->frame_count ? step : scene->duration_ms - frame * step;
+        if (rc == RT_OK) rc = rt_host_animation_add(anim, argb.data(), 1, shown);
+    }
+    const int rc_close = rt_host_animation_close(anim);
+    if (rc != RT_OK || rc_close != RT_OK) fprintf(stderr, "save_scene: %s was not written completely (%s)\n", filename, rt_status_string(rc != RT_OK ? rc : rc_close));
 }
 
 void destroy_scene(Scene* scene) {                                                              // scene.c:227-239
@@ -450,6 +470,8 @@ int rt_host_upscale_frame(Scene* scene, int index, uint32_t* argb) {            
 }
 
 void rt_host_set_obj_mode(int tolerant) { g_obj_mode = tolerant ? 1 : 0; }
+
+void rt_host_set_save_options(float quality, int threads) { g_save_quality = quality > 100.0f ? 100.0f : quality; g_save_threads = threads; }
 
 int rt_host_write_ppm(const Scene* scene, int index, const char* filename) {
     if (!scene || !filename || index < 0 || index >= scene->frame_count) return RT_ERR_INVALID;

@@ -142,6 +142,20 @@ void rt_host_set_obj_mode(int tolerant);
  * argb receives scaled_width*scaled_height words, 0xFF000000 | r<<16 | g<<8 | b, upscaled on the GPU. */
 int rt_host_scaled_size(const Scene* scene, int* scaled_width, int* scaled_height);
 int rt_host_upscale_frame(Scene* scene, int index, uint32_t* argb);
+/* Animation file writer behind save_scene (scene.c:164-224), usable on its own for frames that arrive
+ * one by one (e.g. from other GPUs).  Frames are encoded as full-canvas key frames on `threads` host
+ * threads (0: one per core, at most 16) while the caller produces the next ones, and appended in order.
+ * quality in [0,100] is libwebp's lossy quality factor (WebPConfigInit's default is 75), negative = lossless.
+ * add() copies the frame and returns; format 0 = RGB8 (the layout of Scene.frames), 1 = ARGB32 words
+ * (the layout of WebPPicture.argb).  Without a WebP encoder in the process (rt_host_animation_has_webp() == 0)
+ * the same calls write concatenated binary PPM images to `filename` + ".ppm". */
+typedef struct rt_host_animation rt_host_animation;
+int rt_host_animation_has_webp(void);
+int rt_host_animation_open(const char* filename, int width, int height, float quality, int threads, rt_host_animation** out);
+int rt_host_animation_add(rt_host_animation* a, const void* pixels, int format, int duration_ms);
+int rt_host_animation_close(rt_host_animation* a);
+/* Encoder settings save_scene uses: quality as above (default 75), threads as above (default 0). */
+void rt_host_set_save_options(float quality, int threads);
 
 #ifdef __cplusplus
 }

@@ -88,7 +88,8 @@ EXPORTS = [
     "sample_mesh_texture", "create_bvh_node", "create_bvh", "destroy_bvh_node", "destroy_bvh", "create_camera",
     "create_directional_light", "rt_host_set_device", "rt_host_last_status", "rt_host_render_debug",
     "rt_host_demo_animation", "rt_host_write_ppm", "rt_host_scaled_size", "rt_host_upscale_frame",
-    "rt_host_set_obj_mode",
+    "rt_host_set_obj_mode", "rt_host_animation_has_webp", "rt_host_animation_open", "rt_host_animation_add",
+    "rt_host_animation_close", "rt_host_set_save_options",
 ]
 
 _lib = None
@@ -144,6 +145,16 @@ def lib():
         L.rt_host_demo_animation.restype = None
         L.rt_host_demo_animation.argtypes = [C.c_int, C.POINTER(Transform), C.POINTER(Transform)]
         L.rt_host_write_ppm.argtypes = [C.POINTER(Scene), C.c_int, C.c_char_p]
+        L.rt_host_animation_has_webp.restype = C.c_int
+        L.rt_host_animation_has_webp.argtypes = []
+        L.rt_host_animation_open.restype = C.c_int
+        L.rt_host_animation_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_host_animation_add.restype = C.c_int
+        L.rt_host_animation_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.rt_host_animation_close.restype = C.c_int
+        L.rt_host_animation_close.argtypes = [C.c_void_p]
+        L.rt_host_set_save_options.restype = None
+        L.rt_host_set_save_options.argtypes = [C.c_float, C.c_int]
         L.rt_host_set_obj_mode.restype = None
         L.rt_host_set_obj_mode.argtypes = [C.c_int]
         L.rt_host_scaled_size.argtypes = [C.POINTER(Scene), C.POINTER(C.c_int), C.POINTER(C.c_int)]

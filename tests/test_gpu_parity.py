@@ -258,3 +258,99 @@ def test_reference_host_api_end_to_end(po, golden_hashes):
     for m in loaded:
         L.destroy_mesh(C.byref(m))
     L.destroy_scene(C.byref(scene))
+
+
+def test_save_scene_writes_the_upscaled_animation(po, tmp_path):
+    """save_scene (scene.c:162-225): GPU upscale + animation file.  In lossless mode the file, read back by
+    an independent decoder, holds exactly the reference's upscaled frames with the reference's frame times."""
+    import ctypes as C
+    import os
+    Image = pytest.importorskip("PIL.Image")
+    from raytracer_amd import host_api as H
+    L = H.lib()
+    scene = L.create_scene(160, 120, 700, 10, 0.9)                     # 144x108, 7 frames of 100 ms
+    assert (scene.width, scene.height, scene.frame_count) == (144, 108, 7)
+    L.set_scene_camera(C.byref(scene), H.Vec3(-3, 3, -3), H.Vec3(0, 0, 0), H.Vec3(0, 1, 0), 60.0)
+    L.set_scene_light(C.byref(scene), H.Vec3(1, 1, -1), H.Vec3(1.4, 1.4, 1.4))
+    loaded = []
+    for n in NAMES:
+        m = L.create_mesh(os.path.join(H.ASSETS, n + ".obj").encode(), os.path.join(H.ASSETS, n + ".webp").encode())
+        loaded.append(m)
+        L.add_mesh_to_scene(C.byref(scene), m)
+    for frame in range(scene.frame_count):
+        drone, treasure = H.Transform(), H.Transform()
+        L.rt_host_demo_animation(frame * 13, C.byref(drone), C.byref(treasure))
+        L.set_mesh_position(C.byref(scene.meshes[0]), drone.position)
+        L.set_mesh_rotation(C.byref(scene.meshes[0]), drone.rotation)
+        L.render_scene(C.byref(scene))
+        assert L.rt_host_last_status(C.byref(scene)) == 0
+        L.next_frame(C.byref(scene))
+    rendered = [H.frame_array(scene, f).copy() for f in range(scene.frame_count)]
+    assert not np.array_equal(rendered[0], rendered[3])
+    path = str(tmp_path / "out.webp")
+    L.rt_host_set_save_options(-1.0, 3)
+    L.save_scene(C.byref(scene), path.encode())
+    L.rt_host_set_save_options(75.0, 0)
+    im = Image.open(path)
+    sw, sh = po.scaled_size(scene.width, scene.height, scene.scale_factor)
+    assert im.size == (sw, sh) == (160, 120) and im.n_frames == 7
+    for f in range(7):
+        im.seek(f)
+        im.load()                                                    # the frame time is known once the frame is decoded
+        assert im.info["duration"] == 100
+        want = po.upscale_frame(rendered[f], sw, sh)
+        want_rgb = np.stack([(want >> 16) & 0xFF, (want >> 8) & 0xFF, want & 0xFF], axis=-1).astype(np.uint8)
+        assert np.array_equal(np.asarray(im.convert("RGB")), want_rgb), f
+    # default settings: lossy like the reference's WebPConfigInit, still seven frames
+    L.save_scene(C.byref(scene), path.encode())
+    assert Image.open(path).n_frames == 7
+    for m in loaded:
+        L.destroy_mesh(C.byref(m))
+    L.destroy_scene(C.byref(scene))
+
+
+def test_animation_sink_consumes_gathered_batches(po, tmp_path):
+    """Frames go from the gather's consume hook through the GPU upscale into the animation file while later
+    batches render; the per-rank batches of one gather interleave to consecutive frames."""
+    import torch
+    Image = pytest.importorskip("PIL.Image")
+    from raytracer_amd import animation, demo, sharding
+    dev = torch.device("cuda:0")
+    scene = demo.DemoScene(0)
+    w, h, n, batch = 144, 108, 10, 4
+    path = str(tmp_path / "sink.webp")
+    frames_dev = []
+    with animation.AnimationSink(scene.ctx, path, w, h, 0.9, n, 1000, quality=-1.0, threads=2) as sink:
+        gather = sharding.FrameGather(0, 1, ring=2, consume=sink.consume_gathered(1))
+        for b in range((n + batch - 1) // batch):                       # the last batch carries two padding frames
+            buf = torch.empty((batch, h, w, 3), dtype=torch.uint8, device=dev)
+            scene.render_frames([min(b * batch + k, n - 1) * 7 for k in range(batch)], w, h, buf)
+            scene.ctx.sync()
+            frames_dev.append(buf)
+            gather.submit(buf)
+        gather.finish()
+        assert sink.written == n
+    rendered = torch.cat(frames_dev)[:n].cpu().numpy()
+    im = Image.open(path)
+    assert im.n_frames == n and im.size == (160, 120)
+    for f in range(n):
+        im.seek(f)
+        im.load()                                                    # the frame time is known once the frame is decoded
+        assert im.info["duration"] == 100
+        want = po.upscale_frame(rendered[f], 160, 120)
+        want_rgb = np.stack([(want >> 16) & 0xFF, (want >> 8) & 0xFF, want & 0xFF], axis=-1).astype(np.uint8)
+        assert np.array_equal(np.asarray(im.convert("RGB")), want_rgb), f
+
+    # two ranks' batches of one gather: rank r holds frames r, r+2, ...
+    path2 = str(tmp_path / "two.webp")
+    with animation.AnimationSink(scene.ctx, path2, w, h, 1.0, 8, 800, quality=-1.0, threads=2) as sink:
+        consume = sink.consume_gathered(2)
+        all8 = torch.cat(frames_dev)[:8]
+        consume(0, [all8[0:4:2], all8[1:4:2]])
+        consume(1, [all8[4:8:2], all8[5:8:2]])
+    im = Image.open(path2)
+    assert im.n_frames == 8 and im.size == (w, h)
+    for f in range(8):
+        im.seek(f)
+        assert np.array_equal(np.asarray(im.convert("RGB")), rendered[f]), f     # scale 1: the upscale is the identity
+    scene.close()
