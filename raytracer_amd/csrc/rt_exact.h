@@ -33,6 +33,12 @@ RT_HD F3 unit(F3 a) { return scale(a, 1.0f / sqrtf(dot(a, a))); }
 RT_HD F3 mul(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }            // vec3.c:39
 RT_HD F3 recip(F3 a) { return f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z); }             // aabb.c:34-38
 
+// fminf/fmaxf as the reference's C library evaluates them where the result is stored (box bounds, aabb.c:10-23):
+// of two equal operands -- +0 and -0 -- the second is returned, and a NaN second operand is ignored.
+// Compilers that expand fminf inline pick the other zero.
+RT_HD float min_later(float a, float b) { return (a < b || b != b) ? a : b; }
+RT_HD float max_later(float a, float b) { return (a > b || b != b) ? a : b; }
+
 // aabb.c:33-56 with the reciprocals passed in (same values the reference recomputes per call).
 // fminf/fmaxf return the non-NaN operand, which the zero-extent boxes of flat meshes rely on
 // (0 * inf = NaN inside the slab arithmetic).

@@ -40,8 +40,8 @@ public:
         for (int32_t i = 0; i < count; i++) {
             const rt_vec3* corner = &tris_[start + i].v0;                             // v0, v1, v2 are contiguous
             for (int c = 0; c < 3; c++) {                                             // aabb.c:10-23
-                lo[0] = fminf(lo[0], corner[c].x); lo[1] = fminf(lo[1], corner[c].y); lo[2] = fminf(lo[2], corner[c].z);
-                hi[0] = fmaxf(hi[0], corner[c].x); hi[1] = fmaxf(hi[1], corner[c].y); hi[2] = fmaxf(hi[2], corner[c].z);
+                lo[0] = min_later(lo[0], corner[c].x); lo[1] = min_later(lo[1], corner[c].y); lo[2] = min_later(lo[2], corner[c].z);
+                hi[0] = max_later(hi[0], corner[c].x); hi[1] = max_later(hi[1], corner[c].y); hi[2] = max_later(hi[2], corner[c].z);
             }
         }
         n.bounds_min = {lo[0], lo[1], lo[2]};

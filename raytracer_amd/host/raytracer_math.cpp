@@ -74,8 +74,8 @@ AABB create_empty_aabb(void) {                                                  
     return b;
 }
 AABB expand_aabb(AABB box, Vec3 p) {                                                  // aabb.c:11-19
-    box.min.x = fminf(box.min.x, p.x); box.min.y = fminf(box.min.y, p.y); box.min.z = fminf(box.min.z, p.z);
-    box.max.x = fmaxf(box.max.x, p.x); box.max.y = fmaxf(box.max.y, p.y); box.max.z = fmaxf(box.max.z, p.z);
+    box.min.x = rt::min_later(box.min.x, p.x); box.min.y = rt::min_later(box.min.y, p.y); box.min.z = rt::min_later(box.min.z, p.z);
+    box.max.x = rt::max_later(box.max.x, p.x); box.max.y = rt::max_later(box.max.y, p.y); box.max.z = rt::max_later(box.max.z, p.z);
     return box;
 }
 AABB get_triangle_bounds(Triangle tri) {                                              // aabb.c:21-26

@@ -115,6 +115,32 @@ def test_rt_bvh_build_equals_reference(capi, po, golden_bvh, name):
     assert np.array_equal(bits(nodes["bmin"]), bits(want["bmin"])) and np.array_equal(bits(nodes["bmax"]), bits(want["bmax"]))
 
 
+def signed_zero_soup(n, seed):
+    """Triangles on a coarse grid with many coordinates that are exactly zero, of either sign."""
+    rng = np.random.default_rng(seed)
+    soup = np.zeros((n, 24), np.float32)
+    v = rng.integers(-2, 3, size=(n, 9)).astype(np.float32) * np.float32(0.5)
+    v = np.where((v == 0) & (rng.random((n, 9)) < 0.5), np.float32(-0.0), v)
+    soup[:, :9] = v
+    soup[:, 9:] = rng.random((n, 15), dtype=np.float32)
+    return soup
+
+
+def test_rt_bvh_build_keeps_the_reference_sign_of_zero_bounds(capi, po):
+    """Box bounds are stored results of fminf/fmaxf (aabb.c:10-23): when +0 and -0 meet, the C library the
+    reference is built with returns the later point's zero.  Flat, axis-aligned geometry at 0 hits this."""
+    soup = signed_zero_soup(300, 5)
+    post, nodes = capi.build_bvh(soup)
+    want_t, want_n = po.build_bvh(soup)
+    assert np.array_equal(bits(post), bits(want_t))
+    assert nodes.tobytes() == want_n.tobytes()
+    assert (bits(nodes["bmin"]) == 0x80000000).any() and (bits(nodes["bmin"]) == 0).any()
+    if po.ref_available():
+        R = po.RefScene([soup], [np.zeros((2, 2, 4), np.uint8)])
+        assert R.nodes(0).tobytes() == nodes.tobytes() and np.array_equal(bits(R.triangles(0)), bits(post))
+        R.close()
+
+
 def test_rt_bvh_build_argument_errors(capi):
     L = capi.lib()
     used = C.c_int32(0)
