@@ -96,6 +96,15 @@ const char* rt_status_string(int status);
  * reference does (triangle indices reported by the renderer are indices into that order)
  * and writes the flat node array.  cap >= 2*n is always enough. */
 int rt_bvh_build(rt_triangle* tris, int32_t n, rt_flat_node* nodes_out, int32_t cap, int32_t* n_nodes);
+/* The same build on the GPU of ctx, with the same contract and the same bits in tris and nodes_out
+ * (create_bvh_node, accel/bvh.c:4-59): all nodes of one depth are processed together -- bounds by a
+ * segmented reduction, the centroid mean by one wavefront per node adding in array order (a float sum
+ * cannot be reassociated), the swap-to-front partition by its closed form.  Worth it for meshes of
+ * 10^5 triangles and more; synchronous.  Trees deeper than 256 levels return RT_ERR_UNSUPPORTED
+ * (use rt_bvh_build).  rt_bvh_build_stats: device time (without the copies), tree levels and kernel
+ * launches of the last build; any pointer may be NULL. */
+int rt_bvh_build_device(rt_ctx* ctx, rt_triangle* tris, int32_t n, rt_flat_node* nodes_out, int32_t cap, int32_t* n_nodes);
+int rt_bvh_build_stats(const rt_ctx* ctx, float* device_ms, int32_t* levels, int32_t* launches);
 /* Converts a reference pointer tree (Mesh.bvh.root, geometry/mesh.h:17) to the flat form. */
 int rt_bvh_flatten_tree(const rt_tree_node* root, rt_flat_node* nodes_out, int32_t cap, int32_t* n_nodes);
 

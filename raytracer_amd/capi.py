@@ -58,7 +58,7 @@ NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left", "<i4"), 
                        ("start", "<i4"), ("count", "<i4")])     # rt_flat_node: 40 bytes
 
 EXPORTS = [
-    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_bvh_build", "rt_bvh_flatten_tree",
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_stats", "rt_bvh_flatten_tree",
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
@@ -100,6 +100,8 @@ def lib():
         L.rt_status_string.argtypes = [C.c_int]
         L.rt_status_string.restype = C.c_char_p
         L.rt_bvh_build.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+        L.rt_bvh_build_device.argtypes = [vp, vp, i32, vp, i32, C.POINTER(i32)]
+        L.rt_bvh_build_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(i32)]
         L.rt_bvh_flatten_tree.argtypes = [vp, vp, i32, C.POINTER(i32)]
         L.rt_mesh_upload.argtypes = [vp, vp, i32, vp, i32, vp, i32, i32, C.POINTER(i32)]
         L.rt_mesh_upload_tree.argtypes = [vp, vp, i32, vp, vp, i32, i32, C.POINTER(i32)]
@@ -319,6 +321,20 @@ class Context:
         ms = C.c_float(0)
         self._check(lib().rt_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def build_bvh(self, tris: np.ndarray):
+        """rt_bvh_build_device on a copy: (triangles in post-build order [n,24] f32, nodes NODE_DTYPE), built on the GPU."""
+        t = np.ascontiguousarray(tris, dtype=np.float32).copy()
+        n = int(t.shape[0])
+        nodes = np.zeros(max(2 * n, 1), dtype=NODE_DTYPE)
+        used = C.c_int32(0)
+        self._check(lib().rt_bvh_build_device(self._h, t.ctypes.data, n, nodes.ctypes.data, int(nodes.shape[0]), C.byref(used)))
+        return t, nodes[:used.value].copy()
+
+    def build_stats(self) -> dict:
+        ms, levels, launches = C.c_float(0), C.c_int32(0), C.c_int32(0)
+        self._check(lib().rt_bvh_build_stats(self._h, C.byref(ms), C.byref(levels), C.byref(launches)))
+        return {"device_ms": ms.value, "levels": levels.value, "launches": launches.value}
 
     def last_counters(self) -> dict:
         c = Counters()

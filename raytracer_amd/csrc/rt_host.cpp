@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_build.h"
 #include "rt_kernels.h"
 #include "rt_pack.h"
 
@@ -80,6 +81,8 @@ struct rt_ctx {
     hipEvent_t batch_done[kBatchSlots] = {};
     bool batch_used[kBatchSlots] = {};
     unsigned batch_seq = 0;
+    float build_ms = 0.0f;         // last rt_bvh_build_device
+    int build_levels = 0, build_launches = 0;
     std::string err;
 };
 
@@ -321,6 +324,28 @@ int rt_bvh_build(rt_triangle* tris, int32_t n, rt_flat_node* nodes_out, int32_t 
     BvhBuilder b(tris, nodes_out, cap);
     if (b.build(0, n) < 0) return RT_ERR_CAPACITY;
     *n_nodes = b.used();
+    return RT_OK;
+}
+
+int rt_bvh_build_device(rt_ctx* ctx, rt_triangle* tris, int32_t n, rt_flat_node* nodes_out, int32_t cap, int32_t* n_nodes) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (n < 0 || (n > 0 && !tris) || !nodes_out || !n_nodes || cap < 1) return fail(ctx, RT_ERR_INVALID, "null or negative build arguments");
+    if (n > RT_MAX_MESH_TRIS) return fail(ctx, RT_ERR_UNSUPPORTED, "too many triangles in one mesh");
+    if (n == 0) return rt_bvh_build(tris, 0, nodes_out, cap, n_nodes);          // one empty node, nothing for the GPU to do
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    BuildStats stats;
+    std::string err;
+    const int rc = build_bvh_on_device(tris, n, nodes_out, cap, n_nodes, ctx->stream, err, &stats);
+    if (rc != RT_OK) return fail(ctx, rc, err);
+    ctx->build_ms = stats.device_ms; ctx->build_levels = stats.levels; ctx->build_launches = stats.launches;
+    return RT_OK;
+}
+
+int rt_bvh_build_stats(const rt_ctx* ctx, float* device_ms, int32_t* levels, int32_t* launches) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (device_ms) *device_ms = ctx->build_ms;
+    if (levels) *levels = ctx->build_levels;
+    if (launches) *launches = ctx->build_launches;
     return RT_OK;
 }
 

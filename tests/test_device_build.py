@@ -1,0 +1,120 @@
+"""rt_bvh_build_device: the reference's BVH build (accel/bvh.c:4-59) run level by level on the GPU must
+leave the same bits as the host build -- triangle order and node array -- which in turn is pinned to
+the compiled reference (test_abi_and_host.py, golden BVH arrays)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_abi_and_host import signed_zero_soup
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("drone", "treasure", "ground")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from raytracer_amd import capi as m
+    m.lib()
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def same(capi, ctx, soup):
+    want_t, want_n = capi.build_bvh(soup)
+    got_t, got_n = ctx.build_bvh(soup)
+    assert got_n.shape == want_n.shape
+    assert np.array_equal(got_t.view(np.uint32), want_t.view(np.uint32))
+    assert got_n.tobytes() == want_n.tobytes()
+    return want_n
+
+
+def soup_of(n, seed, spread="uniform"):
+    rng = np.random.default_rng(seed)
+    t = np.zeros((n, 24), np.float32)
+    if spread == "uniform":
+        c = rng.random((n, 1, 3), dtype=np.float32) * 10
+    elif spread == "skewed":                       # means far from medians: one-sided splits, deep trees
+        c = (rng.random((n, 1, 3)) ** 8 * 100).astype(np.float32)
+    elif spread == "outlier":                      # one far triangle drags the mean: all but one key smaller
+        c = rng.random((n, 1, 3), dtype=np.float32)
+        c[n // 2] = 1.0e4
+    elif spread == "grid":                         # many equal keys
+        c = rng.integers(0, 4, size=(n, 1, 3)).astype(np.float32)
+    else:
+        raise ValueError(spread)
+    t[:, :9] = (c + rng.random((n, 3, 3), dtype=np.float32) * 0.1).reshape(n, 9)
+    t[:, 9:] = rng.random((n, 15), dtype=np.float32)
+    return t
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_device_build_equals_host_build_on_the_assets(capi, ctx, po, golden_bvh, name):
+    soup = po.load_obj(os.path.join(po.ASSETS, name + ".obj"))
+    nodes = same(capi, ctx, soup)
+    assert np.array_equal(nodes["left"], golden_bvh[name + "_nodes"]["left"])
+    st = ctx.build_stats()
+    assert st["levels"] >= 2 and st["launches"] > 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 6, 7, 9, 63, 64, 65, 129, 1000, 4097])
+def test_device_build_small_and_ragged_sizes(capi, ctx, n):
+    same(capi, ctx, soup_of(n, n))
+
+
+@pytest.mark.parametrize("spread", ["skewed", "outlier", "grid"])
+def test_device_build_one_sided_and_tied_splits(capi, ctx, spread):
+    for n in (37, 700, 20000):
+        same(capi, ctx, soup_of(n, 11, spread))
+
+
+def test_device_build_sorted_keys(capi, ctx):
+    """Ascending keys: all smaller keys first (no rotation); descending: every smaller key rotates the queue."""
+    n = 3000
+    t = soup_of(n, 3)
+    order = np.argsort(t[:, 0])
+    same(capi, ctx, t[order])
+    same(capi, ctx, t[order[::-1]])
+
+
+def test_device_build_failed_partitions_and_signed_zeros(capi, ctx):
+    one = soup_of(1, 7)
+    same(capi, ctx, np.repeat(one, 9, axis=0))            # nine identical triangles stay one leaf (bvh.c:51-55)
+    same(capi, ctx, np.repeat(one, 300, axis=0))
+    mixed = np.concatenate([np.repeat(one, 40, axis=0), soup_of(200, 8)])
+    same(capi, ctx, mixed)
+    same(capi, ctx, signed_zero_soup(300, 5))
+    same(capi, ctx, signed_zero_soup(5000, 6))
+
+
+def test_device_build_empty_and_argument_errors(capi, ctx):
+    import ctypes as C
+    L = capi.lib()
+    used = C.c_int32(0)
+    nodes = np.zeros(2, capi.NODE_DTYPE)
+    assert L.rt_bvh_build_device(ctx._h, None, 0, nodes.ctypes.data, 2, C.byref(used)) == 0 and used.value == 1
+    tris = soup_of(100, 1)
+    assert L.rt_bvh_build_device(ctx._h, tris.ctypes.data, 100, nodes.ctypes.data, 2, C.byref(used)) == capi.RT_ERR_CAPACITY
+    assert L.rt_bvh_build_device(ctx._h, None, 100, nodes.ctypes.data, 2, C.byref(used)) == capi.RT_ERR_INVALID
+    assert L.rt_bvh_build_device(None, tris.ctypes.data, 100, nodes.ctypes.data, 2, C.byref(used)) == capi.RT_ERR_INVALID
+
+
+def test_device_build_large_mesh_and_render(capi, ctx, po):
+    """Half a million triangles: same bits as the host build, and the uploaded result renders like the host-built one."""
+    import time
+    soup = soup_of(500_000, 21)
+    t0 = time.perf_counter()
+    want_t, want_n = capi.build_bvh(soup)
+    t1 = time.perf_counter()
+    got_t, got_n = ctx.build_bvh(soup)
+    t2 = time.perf_counter()
+    assert np.array_equal(got_t.view(np.uint32), want_t.view(np.uint32)) and got_n.tobytes() == want_n.tobytes()
+    print(f"\n500k triangles: host build {1e3 * (t1 - t0):.0f} ms, device build {1e3 * (t2 - t1):.0f} ms "
+          f"(kernels {ctx.build_stats()['device_ms']:.1f} ms, {ctx.build_stats()['launches']} launches)")
