@@ -118,6 +118,12 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris,
                    const uint8_t* h_rgba, int32_t tex_width, int32_t tex_height, int32_t* mesh_id);
 int rt_mesh_upload_tree(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const rt_tree_node* root,
                         const uint8_t* h_rgba, int32_t tex_width, int32_t tex_height, int32_t* mesh_id);
+/* Replaces the triangles and BVH of an uploaded mesh (same argument meaning as rt_mesh_upload) and keeps
+ * its texture: for a mesh whose vertices change from frame to frame and whose BVH is rebuilt each time
+ * (the reference never does this -- its meshes move by Transform only, raytracer.c:44-53 -- but its data
+ * structures allow it: rebuild with create_bvh / rt_bvh_build / rt_bvh_build_device, then call this).
+ * Waits for frames in flight.  Device arrays are reused when the triangle count is unchanged. */
+int rt_mesh_replace(rt_ctx* ctx, int32_t mesh_id, const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes);
 int rt_scene_clear(rt_ctx* ctx);                                  /* drops all meshes */
 int rt_mesh_count(const rt_ctx* ctx);
 

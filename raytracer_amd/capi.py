@@ -58,7 +58,7 @@ NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left", "<i4"), 
                        ("start", "<i4"), ("count", "<i4")])     # rt_flat_node: 40 bytes
 
 EXPORTS = [
-    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_stats", "rt_bvh_flatten_tree",
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_mesh_replace", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_stats", "rt_bvh_flatten_tree",
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
@@ -105,6 +105,7 @@ def lib():
         L.rt_bvh_flatten_tree.argtypes = [vp, vp, i32, C.POINTER(i32)]
         L.rt_mesh_upload.argtypes = [vp, vp, i32, vp, i32, vp, i32, i32, C.POINTER(i32)]
         L.rt_mesh_upload_tree.argtypes = [vp, vp, i32, vp, vp, i32, i32, C.POINTER(i32)]
+        L.rt_mesh_replace.argtypes = [vp, i32, vp, i32, vp, i32]
         L.rt_scene_clear.argtypes = [vp]
         L.rt_mesh_count.argtypes = [vp]
         L.rt_render_frame.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, u32,
@@ -209,6 +210,13 @@ class Context:
                                          int(nodes.shape[0]), rgba.ctypes.data, int(rgba.shape[1]), int(rgba.shape[0]),
                                          C.byref(mid)))
         return mid.value
+
+    def replace_mesh(self, mesh_id: int, tris: np.ndarray, nodes: np.ndarray):
+        """rt_mesh_replace: new triangles (post-build order) and BVH for an uploaded mesh; the texture stays."""
+        tris = np.ascontiguousarray(tris, dtype=np.float32)
+        nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        assert tris.ndim == 2 and tris.shape[1] == TRI_FLOATS
+        self._check(lib().rt_mesh_replace(self._h, int(mesh_id), tris.ctypes.data, int(tris.shape[0]), nodes.ctypes.data, int(nodes.shape[0])))
 
     def upload_host_mesh(self, mesh) -> int:
         """Uploads a Mesh struct of raytracer_amd.host_api (what create_mesh returns) as it stands."""

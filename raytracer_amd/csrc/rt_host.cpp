@@ -123,6 +123,32 @@ int upload_array(rt_ctx* ctx, const std::vector<T>& src, T** dst) {
     return RT_OK;
 }
 
+// Puts a packed mesh's triangles, attributes and nodes into dm.  Device arrays are reused when the
+// triangle count did not change (a mesh rebuilt every frame); nobody may be reading them.
+int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tris) {
+    const bool reuse = dm.d_tris && dm.d_attrs && dm.n_tris == n_tris && n_tris > 0;
+    if (reuse) {
+        RT_HIP(ctx, hipMemcpy(dm.d_tris, pk.tris.data(), pk.tris.size() * sizeof(TriRec), hipMemcpyHostToDevice));
+        RT_HIP(ctx, hipMemcpy(dm.d_attrs, pk.attrs.data(), pk.attrs.size() * sizeof(AttrRec), hipMemcpyHostToDevice));
+    } else {
+        TriRec* t = nullptr; AttrRec* a = nullptr;
+        int st = upload_array(ctx, pk.tris, &t);
+        if (st == RT_OK) st = upload_array(ctx, pk.attrs, &a);
+        if (st != RT_OK) { if (t) (void)hipFree(t); if (a) (void)hipFree(a); return st; }
+        if (dm.d_tris) (void)hipFree(dm.d_tris);
+        if (dm.d_attrs) (void)hipFree(dm.d_attrs);
+        dm.d_tris = t; dm.d_attrs = a;
+    }
+    dm.pairs = pk.pairs; dm.tris = pk.tris; dm.depth = pk.depth;
+    dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs;
+    memcpy(dm.proto.root_min, pk.root_min, 12);
+    memcpy(dm.proto.root_max, pk.root_max, 12);
+    dm.proto.root_ref = pk.root_ref;
+    dm.proto.empty = pk.empty ? 1u : 0u;
+    dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.pairs.size();
+    return RT_OK;
+}
+
 // Rebuilds the combined node array after the mesh list changed.
 int commit_scene(rt_ctx* ctx) {
     if (!ctx->scene_dirty) return RT_OK;
@@ -370,8 +396,8 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const r
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     DeviceMesh dm;
-    st = upload_array(ctx, pk.tris, &dm.d_tris);
-    if (st == RT_OK) st = upload_array(ctx, pk.attrs, &dm.d_attrs);
+    memset(&dm.proto, 0, sizeof(dm.proto));
+    st = set_geometry(ctx, dm, pk, n_tris);
     if (st == RT_OK) {
         const size_t bytes = (size_t)tex_width * (size_t)tex_height * 4;
         hipError_t e = hipMalloc((void**)&dm.d_texels, bytes);
@@ -379,19 +405,26 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const r
         if (e != hipSuccess) st = hip_fail(ctx, e, "texture upload");
     }
     if (st != RT_OK) { free_mesh(dm); return st; }
-    memset(&dm.proto, 0, sizeof(dm.proto));
-    dm.pairs = pk.pairs; dm.tris = pk.tris; dm.depth = pk.depth;
-    dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs; dm.proto.texels = dm.d_texels;
-    memcpy(dm.proto.root_min, pk.root_min, 12);
-    memcpy(dm.proto.root_max, pk.root_max, 12);
-    dm.proto.root_ref = pk.root_ref;
+    dm.proto.texels = dm.d_texels;
     dm.proto.tex_w = tex_width; dm.proto.tex_h = tex_height;
-    dm.proto.empty = pk.empty ? 1u : 0u;
-    dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.pairs.size();
     ctx->meshes.push_back(dm);
     ctx->scene_dirty = true;
     if (mesh_id) *mesh_id = (int32_t)ctx->meshes.size() - 1;
     return RT_OK;
+}
+
+int rt_mesh_replace(rt_ctx* ctx, int32_t mesh_id, const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (mesh_id < 0 || mesh_id >= (int32_t)ctx->meshes.size()) return fail(ctx, RT_ERR_INVALID, "no such mesh");
+    PackedMesh pk;
+    std::string why;
+    int st = Packer(tris, n_tris, nodes, n_nodes, pk).run(why);
+    if (st != RT_OK) return fail(ctx, st, why);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipDeviceSynchronize());                 // frames in flight still read the old arrays
+    st = set_geometry(ctx, ctx->meshes[(size_t)mesh_id], pk, n_tris);
+    ctx->scene_dirty = true;
+    return st;
 }
 
 int rt_mesh_upload_tree(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const rt_tree_node* root,

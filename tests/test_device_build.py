@@ -118,3 +118,57 @@ def test_device_build_large_mesh_and_render(capi, ctx, po):
     assert np.array_equal(got_t.view(np.uint32), want_t.view(np.uint32)) and got_n.tobytes() == want_n.tobytes()
     print(f"\n500k triangles: host build {1e3 * (t1 - t0):.0f} ms, device build {1e3 * (t2 - t1):.0f} ms "
           f"(kernels {ctx.build_stats()['device_ms']:.1f} ms, {ctx.build_stats()['launches']} launches)")
+
+
+def bake(tris, angle, offset):
+    """Vertices and normals of a triangle soup rotated about y and moved, in float32 (a mesh that deforms on the
+    host; any float recipe will do, GPU and oracle get the same numbers)."""
+    c, s = np.float32(np.cos(angle)), np.float32(np.sin(angle))
+    rot = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32)
+    out = tris.copy()
+    for k in range(3):
+        out[:, 3 * k:3 * k + 3] = (tris[:, 3 * k:3 * k + 3] @ rot.T + np.asarray(offset, np.float32)).astype(np.float32)
+        out[:, 15 + 3 * k:18 + 3 * k] = (tris[:, 15 + 3 * k:18 + 3 * k] @ rot.T).astype(np.float32)
+    return out
+
+
+def test_mesh_rebuilt_every_frame_renders_like_the_reference_loop(capi, ctx, po):
+    """The moving mesh's vertices are rewritten each frame, its BVH is rebuilt (on the GPU and on the host) and
+    swapped in with rt_mesh_replace; frames equal the reference loop's on the same triangles."""
+    import torch
+    meshes = po.default_meshes()
+    soup = po.load_obj(os.path.join(po.ASSETS, "drone.obj"))
+    c = capi.Context(0)
+    for m in meshes:
+        c.upload_mesh(m.tris, m.nodes, m.rgba)
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    pl = po.default_light()
+    light = capi.Light(capi.Vec3(*pl.direction.tup()), capi.Vec3(*pl.color.tup()))
+    w, h = 160, 90
+    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    hid = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+    for frame, builder in ((0, c.build_bvh), (17, capi.build_bvh), (40, c.build_bvh)):
+        baked = bake(soup, 0.05 * frame, (2.0 * np.cos(0.05 * frame), 1.0, 2.0 * np.sin(0.05 * frame)))
+        tris, nodes = builder(baked)
+        c.replace_mesh(0, tris, nodes)
+        t1 = po.animation_transforms(frame)[1]
+        tfs = [capi.Transform(), capi.Transform(capi.Vec3(*t1.position.tup()), capi.Vec3(*t1.rotation.tup())), capi.Transform()]
+        c.render(cam, light, tfs, w, h, rgb, hit_id=hid)
+        c.sync()
+        want_t, want_n = po.build_bvh(baked)
+        ref_meshes = [po.HostMesh(want_t, want_n, meshes[0].rgba), meshes[1], meshes[2]]
+        ptfs = [po.Transform(), po.animation_transforms(frame)[1], po.Transform()]
+        want = po.render_frame(ref_meshes, ptfs, po.default_camera(), po.default_light(), w, h)
+        assert np.array_equal(hid.cpu().numpy(), want.hit_id)
+        assert np.array_equal(rgb.cpu().numpy(), want.rgb)
+        assert (want.hit_id >> 24 == 0).any()                      # the rebuilt mesh is in view
+    # a different triangle count reallocates
+    tris, nodes = capi.build_bvh(bake(soup[:100], 0.3, (0, 1, 0)))
+    c.replace_mesh(0, tris, nodes)
+    c.render(cam, light, tfs, w, h, rgb, hit_id=hid)
+    c.sync()
+    want = po.render_frame([po.HostMesh(tris, nodes, meshes[0].rgba), meshes[1], meshes[2]], ptfs, po.default_camera(), po.default_light(), w, h)
+    assert np.array_equal(hid.cpu().numpy(), want.hit_id) and np.array_equal(rgb.cpu().numpy(), want.rgb)
+    L = capi.lib()
+    assert L.rt_mesh_replace(c._h, 7, tris.ctypes.data, 100, nodes.ctypes.data, int(nodes.shape[0])) == capi.RT_ERR_INVALID
+    c.close()
