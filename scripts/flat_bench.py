@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""The stress scene as ONE mesh: side x side copies of the treasure baked into a single triangle soup
+(about ten million distinct triangles), its BVH built on the GPU (rt_bvh_build_device), uploaded and
+rendered with the plain frame loop next to the ground and the drone.  Unlike the instanced form of the
+scene this working set (nodes + triangles + attributes, ~1.3 GB) does not fit any cache: the traversal
+reads HBM.  One JSON line; --check WxH also compares a small frame with the CPU oracle.
+
+    python scripts/flat_bench.py --side 56 --frames 0,45 --check 96x54
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def baked_grid(soup, side, spacing, seed):
+    rng = np.random.default_rng(seed)
+    n = soup.shape[0]
+    out = np.empty((side * side * n, 24), np.float32)
+    half = (side - 1) / 2.0
+    k = 0
+    for gx in range(side):
+        for gz in range(side):
+            ang = np.float32(rng.uniform(0, 6.28))
+            c, s = np.float32(np.cos(ang)), np.float32(np.sin(ang))
+            rot = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32)
+            off = np.array([(gx - half) * spacing, 0.45 + 0.1 * rng.uniform(), (gz - half) * spacing], np.float32)
+            blk = out[k * n:(k + 1) * n]
+            blk[:] = soup
+            for v in range(3):
+                blk[:, 3 * v:3 * v + 3] = soup[:, 3 * v:3 * v + 3] @ rot.T + off
+                blk[:, 15 + 3 * v:18 + 3 * v] = soup[:, 15 + 3 * v:18 + 3 * v] @ rot.T
+            k += 1
+    return out
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--side", type=int, default=56)
+    p.add_argument("--spacing", type=float, default=1.05)
+    p.add_argument("--frames", default="0,45")
+    p.add_argument("--reps", type=int, default=5)
+    p.add_argument("--check", default="", help="WxH: compare one small frame with the CPU oracle")
+    p.add_argument("--host-build", action="store_true")
+    p.add_argument("--profile", action="store_true", help="no work-counting launches: the program a profiler is pointed at")
+    a = p.parse_args()
+    from raytracer_amd import capi, demo, host_api
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    scene = demo.DemoScene(0)                                    # for the camera, the light, the animation and the assets
+    treasure = host_api.mesh_triangles(scene.meshes[1])
+    t0 = time.perf_counter()
+    soup = baked_grid(treasure, a.side, a.spacing, 3)
+    t_bake = time.perf_counter() - t0
+    ctx = capi.Context(0)
+    t0 = time.perf_counter()
+    tris, nodes = (capi.build_bvh if a.host_build else ctx.build_bvh)(soup)
+    t_build = time.perf_counter() - t0
+    stats = {} if a.host_build else ctx.build_stats()
+    del soup
+    rgba = [host_api.mesh_texture(m) for m in scene.meshes]
+    t0 = time.perf_counter()
+    ctx.upload_host_mesh(scene.meshes[0])
+    ctx.upload_mesh(tris, nodes, rgba[1])
+    ctx.upload_host_mesh(scene.meshes[2])
+    t_upload = time.perf_counter() - t0
+    W, H = a.width, a.height
+    rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    rows = []
+    for f in [int(x) for x in a.frames.split(",")]:
+        tfs = [scene.transforms(f)[0], capi.Transform(), capi.Transform()]
+        c = {"primary_rays": W * H, "shadow_rays": 0, "slab_tests": 0, "tri_tests": 0}
+        if not a.profile:
+            ctx.render(scene.camera, scene.light, tfs, W, H, rgb, flags=capi.RT_FLAG_COUNT_WORK)
+            ctx.sync()
+            c = ctx.last_counters()
+        ms = []
+        for _ in range(a.reps):
+            ctx.render(scene.camera, scene.light, tfs, W, H, rgb)
+            ctx.sync()
+            ms.append(ctx.last_kernel_ms())
+        t = float(np.median(ms))
+        rays = c["primary_rays"] + c["shadow_rays"]
+        rows.append({"frame": f, "kernel_ms": round(t, 3), "rays": rays, "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1),
+                     "box_tests_per_ray": round(c["slab_tests"] / rays, 1), "triangle_tests_per_ray": round(c["tri_tests"] / rays, 1)})
+    out = {"metric": "Mrays/s (primary+shadow), stress scene as one mesh", "unit": "Mrays/s",
+           "value": round(float(np.mean([r["Mrays_per_s"] for r in rows])), 1),
+           "config": {"workload": f"{W}x{H}, {a.side}x{a.side} treasures baked into one mesh of {tris.shape[0]} triangles ({nodes.shape[0]} nodes) + ground + drone"},
+           "dtype": "f32", "bake_s": round(t_bake, 2), "bvh_build_s": round(t_build, 3), "bvh_build": "host" if a.host_build else "device",
+           "build_stats": stats, "pack_and_upload_s": round(t_upload, 2), "frames": rows}
+    if a.check:
+        cw, ch = [int(x) for x in a.check.split("x")]
+        from oracle import pyoracle as po
+        small = torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev)
+        hid = torch.empty((ch, cw), dtype=torch.int32, device=dev)
+        tfs = [scene.transforms(45)[0], capi.Transform(), capi.Transform()]
+        ctx.render(scene.camera, scene.light, tfs, cw, ch, small, hit_id=hid)
+        ctx.sync()
+        own = po.default_meshes()                                 # the oracle's own load of the same assets
+        meshes = [own[0], po.HostMesh(tris, nodes.astype(po.NODE_DTYPE), rgba[1]), own[2]]
+        ptfs = [po.animation_transforms(45)[0], po.Transform(), po.Transform()]
+        want = po.render_frame(meshes, ptfs, po.default_camera(), po.default_light(), cw, ch)
+        out["oracle_check"] = {"size": a.check, "hit_ids_equal": bool(np.array_equal(hid.cpu().numpy(), want.hit_id)),
+                               "rgb_equal": bool(np.array_equal(small.cpu().numpy(), want.rgb))}
+    print(json.dumps(out), flush=True)
+    ctx.close()
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()
