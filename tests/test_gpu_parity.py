@@ -354,3 +354,26 @@ def test_animation_sink_consumes_gathered_batches(po, tmp_path):
         im.seek(f)
         assert np.array_equal(np.asarray(im.convert("RGB")), rendered[f]), f     # scale 1: the upscale is the identity
     scene.close()
+
+
+def test_whole_animation_equals_the_compiled_reference(capi, ctx, po):
+    """All 96 frames of the reference driver's run (raytracer.c:10-57, 720x540), rendered in batches with
+    rt_render_frames, hash for hash and as one stream (tests/golden/animation_hashes.json)."""
+    import json
+    import os
+    import torch
+    from conftest import GOLDEN
+    gold = json.load(open(os.path.join(GOLDEN, "animation_hashes.json")))
+    w, h, n = gold["width"], gold["height"], len(gold["frames"])
+    cam, light = cam_light(capi, po)
+    buf = torch.empty((16, h, w, 3), dtype=torch.uint8, device="cuda:0")
+    total = hashlib.sha256()
+    for first in range(0, n, 16):
+        fr = list(range(first, min(first + 16, n)))
+        ctx.render_frames(cam, light, [to_capi_tfs(capi, po.animation_transforms(f)) for f in fr], w, h, buf)
+        ctx.sync()
+        got = buf[:len(fr)].cpu().numpy()
+        for k, f in enumerate(fr):
+            assert hashlib.sha256(got[k].tobytes()).hexdigest() == gold["frames"][f], f
+            total.update(got[k].tobytes())
+    assert total.hexdigest() == gold["all_frames_sha256"]

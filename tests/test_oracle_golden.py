@@ -229,3 +229,15 @@ def test_oracle_equals_compiled_reference_on_fresh_placements(po, meshes):
             assert np.array_equal(got.rgb, want.rgb)
     finally:
         scene.close()
+
+
+@pytest.mark.parametrize("frame", [7, 23, 60, 88])
+def test_oracle_matches_animation_hashes(po, meshes, frame):
+    """Frames of the 96-frame run other than the three that have full golden planes."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    gold = json.load(open(os.path.join(GOLDEN, "animation_hashes.json")))
+    fr = po.render_frame(meshes, po.animation_transforms(frame), po.default_camera(), po.default_light(), gold["width"], gold["height"], debug=False)
+    assert hashlib.sha256(fr.rgb.tobytes()).hexdigest() == gold["frames"][frame]
