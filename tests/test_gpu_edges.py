@@ -1,0 +1,85 @@
+"""Edge cases of the plain frame paths on the GPU, each against the CPU oracle's reference loop:
+an empty scene, empty and single-leaf meshes, a leaf too large for one leaf reference (the reference
+keeps a node as a leaf when its partition fails, bvh.c:51-55), coincident meshes (the earlier list
+entry wins, scene.c:76), and the same through rt_render_frames and rt_render_frame_sampled."""
+import numpy as np
+import pytest
+
+from test_host_emul import checker, tri_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from raytracer_amd import capi as m
+    m.lib()
+    return m
+
+
+def camera_light(capi, po):
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    l = po.default_light()
+    return cam, capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
+
+
+def conv(capi, tfs):
+    return [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in tfs]
+
+
+def render_all_ways(capi, po, parts, tfs, w, h):
+    """parts: [(triangles post-build, nodes, rgba)].  Renders with rt_render_frame, rt_render_frames (two frames)
+    and rt_render_frame_sampled (1 sample, 1 light) and checks every result against the oracle."""
+    import torch
+    c = capi.Context(0)
+    for t, n, r in parts:
+        c.upload_mesh(t, n, r)
+    cam, light = camera_light(capi, po)
+    want = po.render_frame([po.HostMesh(np.ascontiguousarray(t, np.float32), n, r) for t, n, r in parts], tfs,
+                           po.default_camera(), po.default_light(), w, h)
+    ctf = conv(capi, tfs)
+    rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    hid = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+    two = torch.zeros((2, h, w, 3), dtype=torch.uint8, device="cuda:0")
+    smp = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    c.render(cam, light, ctf, w, h, rgb, hit_id=hid)
+    c.render_frames(cam, light, [ctf, ctf], w, h, two)
+    c.render_sampled(cam, [light], ctf, w, h, 1, 0, smp)
+    c.sync()
+    assert np.array_equal(hid.cpu().numpy(), want.hit_id)
+    assert np.array_equal(rgb.cpu().numpy(), want.rgb)
+    assert np.array_equal(two[0].cpu().numpy(), want.rgb) and np.array_equal(two[1].cpu().numpy(), want.rgb)
+    assert np.array_equal(smp.cpu().numpy(), want.rgb)
+    c.close()
+    return want
+
+
+def test_empty_scene_is_background(capi, po):
+    want = render_all_ways(capi, po, [], [], 70, 41)
+    assert (want.rgb == 50).all() and (want.hit_id == -1).all()               # scene.c:147-150
+
+
+def test_empty_and_single_leaf_meshes(capi, po, meshes):
+    small = tri_rows([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]], [[-1, -1, 0.5], [1, -1, 0.5], [0, 1, 0.5]]])
+    post, nodes = po.build_bvh(small)
+    e_post, e_nodes = po.build_bvh(np.zeros((0, 24), np.float32))
+    parts = [(post, nodes, checker()), (e_post, e_nodes, checker()), (meshes[2].tris, meshes[2].nodes, meshes[2].rgba)]
+    tfs = [po.Transform(po.vec3(0, 1, 0), po.vec3(0, 0.3, 0)), po.Transform(), po.Transform()]
+    want = render_all_ways(capi, po, parts, tfs, 128, 72)
+    ids = want.hit_id[want.hit_id >= 0] >> 24
+    assert (ids == 0).any() and (ids == 2).any() and not (ids == 1).any()
+
+
+def test_oversize_leaf_and_coincident_meshes(capi, po, meshes):
+    """300 identical triangles stay one leaf in the reference; the first of them is the one reported.  The same
+    mesh uploaded twice at the same place: every hit belongs to the first."""
+    one = tri_rows([[[-1.5, -1, 0], [1.5, -1, 0], [0, 1.5, 0]]])
+    post, nodes = po.build_bvh(np.repeat(one, 300, axis=0))
+    assert nodes.shape[0] == 1 and nodes["count"][0] == 300
+    parts = [(post, nodes, checker()), (post, nodes, checker()), (meshes[2].tris, meshes[2].nodes, meshes[2].rgba)]
+    tf = po.Transform(po.vec3(0, 1.2, 0), po.vec3(0.1, 0.7, 0))
+    want = render_all_ways(capi, po, parts, [tf, tf, po.Transform()], 160, 90)
+    hit = want.hit_id[want.hit_id >= 0]
+    assert ((hit >> 24) == 0).any() and not ((hit >> 24) == 1).any()
+    assert set(np.unique(hit[(hit >> 24) == 0] & 0xFFFFFF).tolist()) == {0}
