@@ -172,6 +172,23 @@ int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light
                             int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed,
                             uint32_t flags, void* d_rgb, void* d_hit_id, void* stream);
 
+/* ---- one frame over several GPUs ---------------------------------------------------------- */
+/* Pixels of a frame are independent (scene.c:58-59), so a frame can be dealt out in strips of eight rows:
+ * the call with (strip_stride, strip_offset) renders strips strip_offset, strip_offset + strip_stride, ...
+ * of the frame (0 <= strip_offset < strip_stride) and writes them one below the other into planes that are
+ * rt_strip_rows(height, strip_stride, strip_offset) rows tall (the frame's last strip may be shorter than
+ * eight rows).  Interleaving balances the load between ranks (sky rows are cheap, rows across a mesh are
+ * not); the caller gathers the shares and puts row r of share k at frame row
+ * ((r / 8) * strip_stride + k) * 8 + r % 8.  Every pixel is the pixel rt_render_frame /
+ * rt_render_frame_sampled would have written.  (1, 0) is the whole frame. */
+int rt_strip_rows(int32_t height, int32_t strip_stride, int32_t strip_offset);
+int rt_render_frame_strips(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
+                           int32_t n_transforms, int32_t width, int32_t height, int32_t strip_stride, int32_t strip_offset, uint32_t flags,
+                           void* d_rgb, void* d_hit_id, void* d_hit_t, void* d_shadow, void* stream);
+int rt_render_frame_sampled_strips(rt_ctx* ctx, const rt_camera* camera, const rt_light* lights, int32_t n_lights, const rt_transform* transforms,
+                                   int32_t n_transforms, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed,
+                                   int32_t strip_stride, int32_t strip_offset, uint32_t flags, void* d_rgb, void* d_hit_id, void* stream);
+
 /* render_scene for a scene whose mesh list is long: the reference's Scene.meshes may hold any number of
  * Mesh values (add_mesh_to_scene, scene.c:31-35), for example the same triangles and BVH under thousands of
  * transforms, and tests every ray against every one of them (scene.c:72-108, 124-139).  Here the uploaded
@@ -238,7 +255,9 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * handed to the cooperative pass), "resident_budget" (variants 5..9: bytes of small meshes staged in LDS),
  * "batch_chunk" (rt_render_frames: consecutive tiles of one frame before the same tiles of the next
  * frame; 0 = four tile rows), "xcd_swizzle" (rt_render_frames: 1 = each XCD gets runs of eight neighbouring
- * tiles, default; 0 = every eighth tile).
+ * tiles, default; 0 = every eighth tile), "sampled_split" (rt_render_frame_sampled with four samples or
+ * more: the samples of a tile are traced by four waves and added up in order instead of one wave looping
+ * over them -- 0 never, 1 when the launch has fewer than 100 000 tiles (default), 2 always).
  * Every setting produces the same image.  Read-only: "n_variants", "default_variant".
  * Unknown names give RT_ERR_INVALID. */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);

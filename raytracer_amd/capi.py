@@ -58,7 +58,7 @@ NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left", "<i4"), 
                        ("start", "<i4"), ("count", "<i4")])     # rt_flat_node: 40 bytes
 
 EXPORTS = [
-    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_mesh_replace", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_stats", "rt_bvh_flatten_tree",
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_strip_rows", "rt_render_frame_strips", "rt_render_frame_sampled_strips", "rt_mesh_replace", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_stats", "rt_bvh_flatten_tree",
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
@@ -116,6 +116,11 @@ def lib():
                                        vp, C.c_size_t, vp]
         L.rt_render_frame_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, i32, i32,
                                               u32, u32, vp, vp, vp]
+        L.rt_strip_rows.argtypes = [i32, i32, i32]
+        L.rt_render_frame_strips.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, i32, i32, u32,
+                                             vp, vp, vp, vp, vp]
+        L.rt_render_frame_sampled_strips.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, i32, i32,
+                                                     u32, i32, i32, u32, vp, vp, vp]
         L.rt_render_frame_instanced.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Instance), i32, i32, i32, u32,
                                                 vp, vp, vp, vp, vp, vp]
         L.rt_render_frame_instanced_host.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Instance), i32, i32, i32, u32, vp]
@@ -145,6 +150,14 @@ def scaled_size(width: int, height: int, scale_factor: float):
     if st != RT_OK:
         raise RtError(st)
     return sw.value, sh.value
+
+
+def strip_rows(height: int, strip_stride: int, strip_offset: int) -> int:
+    """rt_strip_rows: rows of a frame that belong to strips strip_offset, strip_offset + strip_stride, ..."""
+    n = lib().rt_strip_rows(int(height), int(strip_stride), int(strip_offset))
+    if n < 0:
+        raise RtError(n)
+    return n
 
 
 def build_bvh(tris: np.ndarray):
@@ -284,6 +297,25 @@ class Context:
         self._check(lib().rt_render_frame_sampled(self._h, C.byref(camera), larr, len(lights), arr, len(transforms), int(width),
                                                   int(height), int(samples_per_pixel), int(seed) & 0xFFFFFFFF, int(flags),
                                                   _dev_ptr(rgb), _dev_ptr(hit_id), stream))
+
+    def render_strips(self, camera: Camera, light: Light, transforms: Sequence[Transform], width: int, height: int,
+                      strip_stride: int, strip_offset: int, rgb, hit_id=None, hit_t=None, shadow=None, flags: int = 0,
+                      stream: Optional[int] = None):
+        """rt_render_frame_strips: this share of the frame's eight-row strips into planes strip_rows(...) rows tall."""
+        arr = (Transform * max(len(transforms), 1))(*transforms)
+        self._check(lib().rt_render_frame_strips(self._h, C.byref(camera), C.byref(light), arr, len(transforms), int(width), int(height),
+                                                 int(strip_stride), int(strip_offset), int(flags), _dev_ptr(rgb), _dev_ptr(hit_id),
+                                                 _dev_ptr(hit_t), _dev_ptr(shadow), stream))
+
+    def render_sampled_strips(self, camera: Camera, lights: Sequence[Light], transforms: Sequence[Transform], width: int, height: int,
+                              samples_per_pixel: int, seed: int, strip_stride: int, strip_offset: int, rgb, hit_id=None, flags: int = 0,
+                              stream: Optional[int] = None):
+        """rt_render_frame_sampled_strips (see render_strips)."""
+        arr = (Transform * max(len(transforms), 1))(*transforms)
+        larr = (Light * max(len(lights), 1))(*lights)
+        self._check(lib().rt_render_frame_sampled_strips(self._h, C.byref(camera), larr, len(lights), arr, len(transforms), int(width),
+                                                         int(height), int(samples_per_pixel), int(seed) & 0xFFFFFFFF, int(strip_stride),
+                                                         int(strip_offset), int(flags), _dev_ptr(rgb), _dev_ptr(hit_id), stream))
 
     @staticmethod
     def make_instances(mesh_ids: Sequence[int], transforms: Sequence[Transform]):

@@ -81,6 +81,7 @@ struct rt_ctx {
     hipEvent_t batch_done[kBatchSlots] = {};
     bool batch_used[kBatchSlots] = {};
     unsigned batch_seq = 0;
+    int sampled_split = 1;         // sampled frames: the samples of a tile spread over four waves
     float build_ms = 0.0f;         // last rt_bvh_build_device
     int build_levels = 0, build_launches = 0;
     std::string err;
@@ -449,9 +450,29 @@ int rt_scene_clear(rt_ctx* ctx) {
 
 int rt_mesh_count(const rt_ctx* ctx) { return ctx ? (int)ctx->meshes.size() : RT_ERR_INVALID; }
 
-int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
-                    int32_t n_transforms, int32_t width, int32_t height, uint32_t flags, void* d_rgb, void* d_hit_id,
-                    void* d_hit_t, void* d_shadow, void* stream) {
+namespace {
+
+// Rows of a frame `height` rows tall that belong to strips offset, offset + stride, ... (strips of eight rows).
+int32_t strip_rows(int32_t height, int32_t stride, int32_t offset) {
+    const int32_t total = (height + 7) / 8;
+    if (offset >= total) return 0;
+    const int32_t k = (total - offset + stride - 1) / stride;
+    int32_t rows = 8 * k;
+    if (offset + (k - 1) * stride == total - 1 && height % 8) rows -= 8 - height % 8;
+    return rows;
+}
+
+// Turns A (filled for the whole frame) into the launch of one share of its strips.  false: nothing to render.
+bool take_strips(FrameArgs& A, int32_t stride, int32_t offset) {
+    const int32_t rows = strip_rows(A.height, stride, offset);
+    A.full_height = A.height; A.strip_stride = stride; A.strip_offset = offset;
+    A.height = rows;
+    return rows > 0;
+}
+
+int render_frame_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
+                      int32_t n_transforms, int32_t width, int32_t height, int32_t stride, int32_t offset, uint32_t flags, void* d_rgb,
+                      void* d_hit_id, void* d_hit_t, void* d_shadow, void* stream) {
     if (!ctx) return RT_ERR_INVALID;
     if (!camera || !light || !d_rgb) return fail(ctx, RT_ERR_INVALID, "camera, light and d_rgb are required");
     if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
@@ -466,10 +487,14 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
 
     FrameArgs A;
     fill_frame(ctx, *camera, *light, transforms, n_transforms, width, height, flags, A);
+    const bool share = stride != 1 || offset != 0;        // some of the frame's strips: plain tiles in launch order
+    if (share && !take_strips(A, stride, offset)) return RT_OK;
+    LaunchConfig cfg = ctx->cfg;
+    if (share) cfg.variant = 0;
     // Work layout: screen rectangles where rays can meet a big mesh are rendered cooperatively and
     // launched first.  Not used when the caller asks for the reference's visiting order or for work
     // counts, when a rectangle cannot be bounded, or when they cover more than a quarter of the frame.
-    if (ctx->cfg.variant == 3 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER)) == 0 && ctx->coop) {
+    if (cfg.variant == 3 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER)) == 0 && ctx->coop) {
         std::vector<WorldBox> boxes((size_t)n_transforms);
         double slo[3] = {1e300, 1e300, 1e300}, shi[3] = {-1e300, -1e300, -1e300};
         for (int32_t m = 0; m < n_transforms; m++) {
@@ -505,7 +530,7 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    if (ctx->cfg.variant == 4 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER)) == 0) {
+    if (cfg.variant == 4 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER)) == 0) {
         const size_t pixels = (size_t)width * (size_t)height;
         if (pixels > ctx->defer_capacity) {
             RT_HIP(ctx, hipDeviceSynchronize());          // an earlier frame may still be reading the old list
@@ -514,13 +539,13 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
             RT_HIP(ctx, hipMalloc((void**)&ctx->d_defer_items, pixels * sizeof(uint32_t)));
             ctx->defer_capacity = pixels;
         }
-        ctx->cfg.defer = ctx->d_defer;
-        ctx->cfg.defer_items = ctx->d_defer_items;
-        ctx->cfg.defer_capacity = (uint32_t)ctx->defer_capacity;
-        ctx->cfg.parity = (int)(ctx->two_pass_frames++ & 1u);
+        cfg.defer = ctx->d_defer;
+        cfg.defer_items = ctx->d_defer_items;
+        cfg.defer_capacity = (uint32_t)ctx->defer_capacity;
+        cfg.parity = (int)(ctx->two_pass_frames++ & 1u);
         A.defer_budget = ctx->budget;
     }
-    hipError_t le = launch_render(A, S, O, ctx->cfg, s);
+    hipError_t le = launch_render(A, S, O, cfg, s);
     if (le != hipSuccess) {
         // leave the work-distribution words of the persistent / two-pass variants in their idle state
         (void)hipDeviceSynchronize();
@@ -530,6 +555,34 @@ int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
     }
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
     return RT_OK;
+}
+
+int bad_strips(rt_ctx* ctx, int32_t stride, int32_t offset) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (stride < 1 || offset < 0 || offset >= stride) return fail(ctx, RT_ERR_INVALID, "strips: need stride >= 1 and 0 <= offset < stride");
+    return RT_OK;
+}
+
+}  // namespace
+
+int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
+                    int32_t n_transforms, int32_t width, int32_t height, uint32_t flags, void* d_rgb, void* d_hit_id,
+                    void* d_hit_t, void* d_shadow, void* stream) {
+    return render_frame_impl(ctx, camera, light, transforms, n_transforms, width, height, 1, 0, flags, d_rgb, d_hit_id, d_hit_t, d_shadow, stream);
+}
+
+int rt_strip_rows(int32_t height, int32_t strip_stride, int32_t strip_offset) {
+    if (height <= 0 || strip_stride < 1 || strip_offset < 0 || strip_offset >= strip_stride) return RT_ERR_INVALID;
+    return strip_rows(height, strip_stride, strip_offset);
+}
+
+int rt_render_frame_strips(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
+                           int32_t n_transforms, int32_t width, int32_t height, int32_t strip_stride, int32_t strip_offset, uint32_t flags,
+                           void* d_rgb, void* d_hit_id, void* d_hit_t, void* d_shadow, void* stream) {
+    const int st = bad_strips(ctx, strip_stride, strip_offset);
+    if (st != RT_OK) return st;
+    return render_frame_impl(ctx, camera, light, transforms, n_transforms, width, height, strip_stride, strip_offset, flags, d_rgb, d_hit_id,
+                             d_hit_t, d_shadow, stream);
 }
 
 int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms, int32_t n_frames,
@@ -573,9 +626,10 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light
     return RT_OK;
 }
 
-int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light* lights, int32_t n_lights, const rt_transform* transforms,
-                            int32_t n_transforms, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed, uint32_t flags,
-                            void* d_rgb, void* d_hit_id, void* stream) {
+namespace {
+int render_sampled_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* lights, int32_t n_lights, const rt_transform* transforms,
+                        int32_t n_transforms, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed, int32_t stride,
+                        int32_t offset, uint32_t flags, void* d_rgb, void* d_hit_id, void* stream) {
     if (!ctx) return RT_ERR_INVALID;
     if (!camera || !lights || !d_rgb) return fail(ctx, RT_ERR_INVALID, "camera, lights and d_rgb are required");
     if (n_lights < 1 || n_lights > RT_MAX_LIGHTS) return fail(ctx, RT_ERR_UNSUPPORTED, "n_lights must be 1..RT_MAX_LIGHTS");
@@ -594,6 +648,7 @@ int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light
     fill_frame(ctx, *camera, lights[0], transforms, n_transforms, width, height, flags, A);
     SampleArgs X;
     fill_samples(lights, n_lights, samples_per_pixel, seed, A, X);
+    if ((stride != 1 || offset != 0) && !take_strips(A, stride, offset)) return RT_OK;
     OutputPlanes O;
     O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_id; O.hit_t = nullptr; O.shadow = nullptr;
     O.counters = ctx->d_counters; O.tile_clock = nullptr;
@@ -602,10 +657,27 @@ int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    hipError_t le = launch_sampled(A, X, S, O, ctx->cfg.block, s);
+    hipError_t le = launch_sampled(A, X, S, O, ctx->cfg.block, ctx->sampled_split, s);
     if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
     return RT_OK;
+}
+}  // namespace
+
+int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light* lights, int32_t n_lights, const rt_transform* transforms,
+                            int32_t n_transforms, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed, uint32_t flags,
+                            void* d_rgb, void* d_hit_id, void* stream) {
+    return render_sampled_impl(ctx, camera, lights, n_lights, transforms, n_transforms, width, height, samples_per_pixel, seed, 1, 0, flags,
+                               d_rgb, d_hit_id, stream);
+}
+
+int rt_render_frame_sampled_strips(rt_ctx* ctx, const rt_camera* camera, const rt_light* lights, int32_t n_lights, const rt_transform* transforms,
+                                   int32_t n_transforms, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed,
+                                   int32_t strip_stride, int32_t strip_offset, uint32_t flags, void* d_rgb, void* d_hit_id, void* stream) {
+    const int st = bad_strips(ctx, strip_stride, strip_offset);
+    if (st != RT_OK) return st;
+    return render_sampled_impl(ctx, camera, lights, n_lights, transforms, n_transforms, width, height, samples_per_pixel, seed, strip_stride,
+                               strip_offset, flags, d_rgb, d_hit_id, stream);
 }
 
 int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_instance* instances, int32_t n_instances,
@@ -821,6 +893,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "timing")) { ctx->timing = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "coop")) { ctx->coop = value; return RT_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = value ? 1 : 0; return RT_OK; }
+    if (!strcmp(name, "sampled_split")) { ctx->sampled_split = value < 0 ? 0 : (value > 2 ? 2 : value); return RT_OK; }
     if (!strcmp(name, "batch_chunk")) {
         if (value < 0 || value > (1 << 20)) return fail(ctx, RT_ERR_INVALID, "batch_chunk out of range");
         ctx->batch_chunk = value; return RT_OK;
@@ -841,6 +914,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "variant")) { *value = ctx->cfg.variant; return RT_OK; }
     if (!strcmp(name, "block")) { *value = ctx->cfg.block; return RT_OK; }
     if (!strcmp(name, "timing")) { *value = ctx->timing; return RT_OK; }
+    if (!strcmp(name, "sampled_split")) { *value = ctx->sampled_split; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }
     if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }

@@ -62,7 +62,7 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
     InstancedOut out;
     // ---- camera ray (camera.c:12-30) ----
     const float fx = ((float)px + 0.5f) / (float)A.width;
-    const float fy = ((float)py + 0.5f) / (float)A.height;
+    const float fy = ((float)frame_row(A, py) + 0.5f) / (float)A.full_height;
     const float rx = (2.0f * fx - 1.0f) * A.aspect * A.scale;
     const float ry = (1.0f - 2.0f * fy) * A.scale;
     const F3 wo = f3(A.cam_pos);

@@ -42,7 +42,7 @@ hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int 
 
 // Enqueues one sampled frame (X.spp camera rays per pixel, X.n_lights lights).  O.rgb is required,
 // O.hit_id optional (sample 0), the other planes are not written.  block: 64 or 256.
-hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneArgs& S, const OutputPlanes& O, int block, hipStream_t stream);
+hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneArgs& S, const OutputPlanes& O, int block, int split, hipStream_t stream);
 
 // Enqueues one frame of an instanced scene.  I.inst holds one MeshArgs per instance (pair ranges inside
 // S.pairs, live tris/attrs/texels), I.tlas / I.order the hierarchy over the non-empty ones, its depth at

@@ -169,13 +169,92 @@ __global__ void __launch_bounds__(BLOCK) render_sampled(const FrameArgs A, const
     }
 }
 
-hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneArgs& S, const OutputPlanes& O, int block, hipStream_t stream) {
+// The same frame with the samples of a tile spread over the four waves of a workgroup: wave w traces
+// samples w, w + 4, ... of the tile's 64 pixels and leaves their values in LDS; wave 0 adds them up in
+// sample order (the order is part of the result) and writes the pixel.  The longest dependent chain of a
+// launch drops from spp samples to spp / 4, which matters when a launch has few tiles (a share of a
+// frame split over GPUs) and at the end of every launch.
+constexpr int kSplitWaves = 4;
+
+template <bool COUNT>
+__global__ void __launch_bounds__(64 * kSplitWaves) render_sampled_split(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
+    constexpr int BLOCK = 64 * kSplitWaves;
+    __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
+    extern __shared__ float lds_values[];                       // [spp][3][64]
+    __shared__ uint32_t lds_counts[kSplitWaves][2][64];
+    __shared__ int32_t lds_hit_id[64];
+    LdsStack<BLOCK> stack;
+    stack.init(&lds_stack[threadIdx.x]);
+    GlobalNodes nodes; nodes.all = S.pairs;
+    const int tiles_x = (A.width + 7) >> 3;
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int px, py;
+    tile_pixel(tile, lane, tiles_x, px, py);
+    const bool inside = px < A.width && py < A.height;
+    LaneTotals tot = {0, 0, 0, 0, 0};
+    SampledOut out;
+    out.hits = 0; out.darks = 0; out.hit_id = -1;
+    Work work; work.slabs = 0; work.tris = 0;
+    if (inside) {
+        const int row = frame_row(A, py);
+        for (int s = wave; s < X.spp; s += kSplitWaves) {
+            const F3 v = sample_value<COUNT>(A, X, nodes, Solo(), px, row, s, stack, work, out);
+            float* slot = lds_values + (size_t)s * 192 + lane;
+            slot[0] = v.x; slot[64] = v.y; slot[128] = v.z;
+        }
+    }
+    lds_counts[wave][0][lane] = out.hits; lds_counts[wave][1][lane] = out.darks;
+    if (wave == 0) lds_hit_id[lane] = out.hit_id;
+    __syncthreads();
+    if (wave == 0 && inside) {
+        F3 acc = f3(0.0f, 0.0f, 0.0f);
+        for (int s = 0; s < X.spp; s++) {
+            const float* slot = lds_values + (size_t)s * 192 + lane;
+            const F3 v = f3(slot[0], slot[64], slot[128]);
+            acc = s == 0 ? v : add(acc, v);
+        }
+        finish_sampled(X, acc, out);
+        const size_t p = (size_t)py * (size_t)A.width + (size_t)px;
+        uint8_t* rgb = O.rgb + p * 3;
+        rgb[0] = out.r; rgb[1] = out.g; rgb[2] = out.b;
+        if (O.hit_id) O.hit_id[p] = lds_hit_id[lane];
+        uint32_t hits = 0, darks = 0;
+        for (int w = 0; w < kSplitWaves; w++) { hits += lds_counts[w][0][lane]; darks += lds_counts[w][1][lane]; }
+        tot.pixels = (unsigned long long)X.spp; tot.hits = hits; tot.darks = darks;
+    }
+    if (COUNT) {
+        tot.slabs = work.slabs; tot.tris = work.tris;
+        const unsigned long long prim = wave_sum(tot.pixels), hit = wave_sum(tot.hits), dark = wave_sum(tot.darks);
+        const unsigned long long slabs = wave_sum(tot.slabs), tris = wave_sum(tot.tris);
+        if (lane == 0) {
+            if (wave == 0) {
+                atomicAdd(&O.counters->primary_rays, prim);
+                atomicAdd(&O.counters->shadow_rays, hit * (unsigned long long)X.n_lights);
+                atomicAdd(&O.counters->hit_pixels, hit);
+                atomicAdd(&O.counters->shadowed_pixels, dark);
+            }
+            atomicAdd(&O.counters->slab_tests, slabs);
+            atomicAdd(&O.counters->tri_tests, tris);
+        }
+    }
+}
+
+hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneArgs& S, const OutputPlanes& O, int block, int split, hipStream_t stream) {
     if (A.width <= 0 || A.height <= 0 || X.spp < 1 || X.spp > kMaxSamples || X.n_lights < 1 || X.n_lights > kMaxLights || !O.rgb)
         return hipErrorInvalidValue;
     const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
     if (count && !O.counters) return hipErrorInvalidValue;
     const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
-    if (block == 256) {
+    const size_t dyn = (size_t)X.spp * 192 * sizeof(float);
+    const size_t fixed = (size_t)kStackDepth * 64 * kSplitWaves * sizeof(uint32_t) + 4096;
+    // split = 1: when the launch has too few tiles to hide a tile's sample loop behind other tiles (measured at
+    // 16 samples: 65 k tiles 6.1 ms split / 7.2 ms looped, 130 k tiles 12.0 / 9.9); 2: always.
+    const bool want = split == 2 || (split == 1 && tiles <= 100000);
+    if (want && X.spp >= kSplitWaves && dyn + fixed <= 64 * 1024) {      // 64 KB of LDS per workgroup without opting in to more
+        if (count) hipLaunchKernelGGL((render_sampled_split<true>), dim3(tiles), dim3(64 * kSplitWaves), dyn, stream, A, X, S, O);
+        else       hipLaunchKernelGGL((render_sampled_split<false>), dim3(tiles), dim3(64 * kSplitWaves), dyn, stream, A, X, S, O);
+    } else if (block == 256) {
         const int blocks = (tiles + 3) / 4;
         if (count) hipLaunchKernelGGL((render_sampled<256, true>), dim3(blocks), dim3(256), 0, stream, A, X, S, O);
         else       hipLaunchKernelGGL((render_sampled<256, false>), dim3(blocks), dim3(256), 0, stream, A, X, S, O);

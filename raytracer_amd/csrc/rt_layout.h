@@ -87,7 +87,12 @@ constexpr uint32_t kNotResident = 0xFFFFFFFFu;
 constexpr uint32_t kResidentBudget = 32 * 1024;
 
 struct FrameArgs {
+    // height = rows this launch renders (and the rows of its output planes).  A launch may render every
+    // strip_stride-th strip of eight rows of a frame full_height rows tall, starting with strip
+    // strip_offset (one rank's share of a frame split over several GPUs): row py of the launch is row
+    // frame_row(py) of the frame.  A whole frame is full_height = height, stride 1, offset 0.
     int32_t width, height;
+    int32_t full_height, strip_stride, strip_offset, pad_rows;
     int32_t n_mesh;
     uint32_t flags;
     float cam_pos[3];

@@ -286,6 +286,9 @@ struct PixelOut {
     uint32_t deferred;   // 1: not rendered, the party ran out of budget (DEFER only)
 };
 
+// Row of the whole frame that row py of this launch is (see FrameArgs).
+RT_HD int frame_row(const FrameArgs& A, int py) { return ((py >> 3) * A.strip_stride + A.strip_offset) * 8 + (py & 7); }
+
 // DEFER=true gives up as soon as the party reports that its budget is exhausted and returns with
 // `deferred` set; nothing of such a pixel is stored.
 template <bool COUNT, bool FULL, bool DEFER, class Stack, class Nodes, class Party>
@@ -294,7 +297,7 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     out.deferred = 0;
     // ---- camera ray (camera.c:12-30; basis and tan() hoisted to the host) ----
     const float fx = ((float)px + 0.5f) / (float)A.width;             // scene.c:61
-    const float fy = ((float)py + 0.5f) / (float)A.height;            // scene.c:62
+    const float fy = ((float)frame_row(A, py) + 0.5f) / (float)A.full_height;   // scene.c:62
     const float rx = (2.0f * fx - 1.0f) * A.aspect * A.scale;         // camera.c:18
     const float ry = (1.0f - 2.0f * fy) * A.scale;                    // camera.c:19
     const F3 wo = f3(A.cam_pos);

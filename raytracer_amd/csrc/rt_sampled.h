@@ -42,76 +42,91 @@ struct SampledOut {
     int32_t hit_id;      // of sample 0: (mesh<<24)|tri or -1
 };
 
+// Value of sample s of pixel (px, row of the whole frame): three floats in [0, 255].  Adds to hits / darks;
+// sample 0 sets hit_id.
+template <bool COUNT, class Stack, class Nodes, class Party>
+RT_HD F3 sample_value(const FrameArgs& A, const SampleArgs& X, const Nodes& nodes, const Party& party, int px, int row, int s,
+                      Stack& stack, Work& work, SampledOut& out) {
+    const F3 wo = f3(A.cam_pos);
+    float jx = 0.5f, jy = 0.5f;
+    if (X.spp > 1) sample_offset((uint32_t)px, (uint32_t)row, (uint32_t)s, X.seed, jx, jy);
+    // ---- camera ray (scene.c:61-62 with the offset in place of 0.5f; camera.c:12-30) ----
+    const float fx = ((float)px + jx) / (float)A.width;
+    const float fy = ((float)row + jy) / (float)A.full_height;
+    const float rx = (2.0f * fx - 1.0f) * A.aspect * A.scale;
+    const float ry = (1.0f - 2.0f * fy) * A.scale;
+    const F3 wd = unit(add(add(scale(f3(A.cam_right), rx), scale(f3(A.cam_up), ry)), f3(A.cam_fwd)));
+
+    // ---- closest hit over the meshes (scene.c:72-108) ----
+    float closest = 1e30f;
+    int who = -1;
+    Hit best = no_hit();
+    for (int m = 0; m < A.n_mesh; m++) {
+        const MeshArgs& M = A.mesh[m];
+        const F3 ld = unit(xform_vector<4>(M.inv, wd));
+        Hit h = no_hit();
+        if (party.template closest<COUNT, false>(M, nodes, f3(M.cam_o), ld, recip(ld), closest, h, stack, work) && h.t < closest) {
+            closest = h.t; who = m; best = h;
+        }
+    }
+    F3 value = f3(50.0f, 50.0f, 50.0f);                                   // scene.c:156
+    if (who >= 0) {
+        const MeshArgs& M = A.mesh[who];
+        out.hits++;
+        if (s == 0) out.hit_id = (int32_t)(((uint32_t)who << 24) | best.tri);
+        // ---- attributes and texel of the hit (scene.c:86-106, mesh.c:138-149) ----
+        const AttrRec& R = M.attrs[best.tri];
+        const float u = best.u, v = best.v;
+        const float w = 1.0f - u - v;
+        const float tu = w * R.t0[0] + u * R.t1[0] + v * R.t2[0];
+        const float tv = w * R.t0[1] + u * R.t1[1] + v * R.t2[1];
+        F3 n = unit(add(add(scale(f3(R.n0), w), scale(f3(R.n1), u)), scale(f3(R.n2), v)));
+        n = unit(xform_vector<3>(M.nrm, n));
+        const float su = tu - floorf(tu), sv = tv - floorf(tv);
+        const int tx = (int)(su * (float)(M.tex_w - 1));
+        const int ty = (int)(sv * (float)(M.tex_h - 1));
+        const uint32_t texel = M.texels[ty * M.tex_w + tx];
+        const F3 tex = f3((float)(texel & 0xFFu) / 255.0f, (float)((texel >> 8) & 0xFFu) / 255.0f,
+                          (float)((texel >> 16) & 0xFFu) / 255.0f);
+        // ---- one shadow ray per light (scene.c:117-149) ----
+        const F3 so = add(add(wo, scale(wd, closest)), scale(n, 0.001f));
+        F3 color = f3(0.0f, 0.0f, 0.0f);
+        for (int l = 0; l < X.n_lights; l++) {
+            bool dark = false;
+            for (int m = 0; m < A.n_mesh && !dark; m++) {
+                const MeshArgs& S = A.mesh[m];
+                const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);
+                dark = party.template any<COUNT, false>(S, nodes, lo, f3(X.lit_d[m][l]), f3(X.lit_inv[m][l]), stack, work);
+            }
+            float diffuse = 0.2f;
+            if (!dark) diffuse = fmaxf(diffuse, dot(n, f3(X.light_dir[l])));
+            else out.darks++;
+            const F3 term = scale(mul(tex, f3(X.light_color[l])), diffuse);
+            color = l == 0 ? term : add(color, term);
+        }
+        value = f3(fminf(color.x * 255.0f, 255.0f), fminf(color.y * 255.0f, 255.0f), fminf(color.z * 255.0f, 255.0f));
+    }
+    return value;
+}
+
+// Sum of the sample values in order -> bytes.
+RT_HD void finish_sampled(const SampleArgs& X, F3 acc, SampledOut& out) {
+    if (X.spp > 1) { const float n = (float)X.spp; acc = f3(acc.x / n, acc.y / n, acc.z / n); }
+    out.r = (uint8_t)acc.x; out.g = (uint8_t)acc.y; out.b = (uint8_t)acc.z;
+}
+
 template <bool COUNT, class Stack, class Nodes, class Party>
 RT_HD SampledOut shade_sampled_pixel(const FrameArgs& A, const SampleArgs& X, const Nodes& nodes, const Party& party, int px, int py,
                                      Stack& stack, Work& work) {
     SampledOut out;
     out.hits = 0; out.darks = 0; out.hit_id = -1;
-    const F3 wo = f3(A.cam_pos);
+    const int row = frame_row(A, py);          // the pixel's row in the whole frame
     F3 acc = f3(0.0f, 0.0f, 0.0f);
     for (int s = 0; s < X.spp; s++) {
-        float jx = 0.5f, jy = 0.5f;
-        if (X.spp > 1) sample_offset((uint32_t)px, (uint32_t)py, (uint32_t)s, X.seed, jx, jy);
-        // ---- camera ray (scene.c:61-62 with the offset in place of 0.5f; camera.c:12-30) ----
-        const float fx = ((float)px + jx) / (float)A.width;
-        const float fy = ((float)py + jy) / (float)A.height;
-        const float rx = (2.0f * fx - 1.0f) * A.aspect * A.scale;
-        const float ry = (1.0f - 2.0f * fy) * A.scale;
-        const F3 wd = unit(add(add(scale(f3(A.cam_right), rx), scale(f3(A.cam_up), ry)), f3(A.cam_fwd)));
-
-        // ---- closest hit over the meshes (scene.c:72-108) ----
-        float closest = 1e30f;
-        int who = -1;
-        Hit best = no_hit();
-        for (int m = 0; m < A.n_mesh; m++) {
-            const MeshArgs& M = A.mesh[m];
-            const F3 ld = unit(xform_vector<4>(M.inv, wd));
-            Hit h = no_hit();
-            if (party.template closest<COUNT, false>(M, nodes, f3(M.cam_o), ld, recip(ld), closest, h, stack, work) && h.t < closest) {
-                closest = h.t; who = m; best = h;
-            }
-        }
-        F3 value = f3(50.0f, 50.0f, 50.0f);                                   // scene.c:156
-        if (who >= 0) {
-            const MeshArgs& M = A.mesh[who];
-            out.hits++;
-            if (s == 0) out.hit_id = (int32_t)(((uint32_t)who << 24) | best.tri);
-            // ---- attributes and texel of the hit (scene.c:86-106, mesh.c:138-149) ----
-            const AttrRec& R = M.attrs[best.tri];
-            const float u = best.u, v = best.v;
-            const float w = 1.0f - u - v;
-            const float tu = w * R.t0[0] + u * R.t1[0] + v * R.t2[0];
-            const float tv = w * R.t0[1] + u * R.t1[1] + v * R.t2[1];
-            F3 n = unit(add(add(scale(f3(R.n0), w), scale(f3(R.n1), u)), scale(f3(R.n2), v)));
-            n = unit(xform_vector<3>(M.nrm, n));
-            const float su = tu - floorf(tu), sv = tv - floorf(tv);
-            const int tx = (int)(su * (float)(M.tex_w - 1));
-            const int ty = (int)(sv * (float)(M.tex_h - 1));
-            const uint32_t texel = M.texels[ty * M.tex_w + tx];
-            const F3 tex = f3((float)(texel & 0xFFu) / 255.0f, (float)((texel >> 8) & 0xFFu) / 255.0f,
-                              (float)((texel >> 16) & 0xFFu) / 255.0f);
-            // ---- one shadow ray per light (scene.c:117-149) ----
-            const F3 so = add(add(wo, scale(wd, closest)), scale(n, 0.001f));
-            F3 color = f3(0.0f, 0.0f, 0.0f);
-            for (int l = 0; l < X.n_lights; l++) {
-                bool dark = false;
-                for (int m = 0; m < A.n_mesh && !dark; m++) {
-                    const MeshArgs& S = A.mesh[m];
-                    const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);
-                    dark = party.template any<COUNT, false>(S, nodes, lo, f3(X.lit_d[m][l]), f3(X.lit_inv[m][l]), stack, work);
-                }
-                float diffuse = 0.2f;
-                if (!dark) diffuse = fmaxf(diffuse, dot(n, f3(X.light_dir[l])));
-                else out.darks++;
-                const F3 term = scale(mul(tex, f3(X.light_color[l])), diffuse);
-                color = l == 0 ? term : add(color, term);
-            }
-            value = f3(fminf(color.x * 255.0f, 255.0f), fminf(color.y * 255.0f, 255.0f), fminf(color.z * 255.0f, 255.0f));
-        }
+        const F3 value = sample_value<COUNT>(A, X, nodes, party, px, row, s, stack, work, out);
         acc = s == 0 ? value : add(acc, value);
     }
-    if (X.spp > 1) { const float n = (float)X.spp; acc = f3(acc.x / n, acc.y / n, acc.z / n); }
-    out.r = (uint8_t)acc.x; out.g = (uint8_t)acc.y; out.b = (uint8_t)acc.z;
+    finish_sampled(X, acc, out);
     return out;
 }
 

@@ -130,3 +130,59 @@ def render_sharded(n_frames: int, rank: int, world: int, height: int, width: int
                 if i < len(theirs):
                     frames[theirs[i]] = t[k]
     return frames
+
+
+# ------------------------------------------------------------------------------------------------
+# One frame over several ranks: strips of eight rows dealt round-robin (pixels are independent,
+# reference scene.c:58-59).  Rank r renders strips r, r + N, ... with rt_render_frame_strips /
+# rt_render_frame_sampled_strips into a plane strip_rows(height, N, r) rows tall; the shares are
+# gathered on rank 0 and interleaved back into the frame.
+# ------------------------------------------------------------------------------------------------
+def strip_rows(height: int, world: int, rank: int) -> int:
+    """Rows of a `height`-row frame in strips rank, rank + world, ... (what rt_strip_rows returns)."""
+    total = (height + 7) // 8
+    if rank >= total:
+        return 0
+    k = (total - rank + world - 1) // world
+    rows = 8 * k
+    if rank + (k - 1) * world == total - 1 and height % 8:
+        rows -= 8 - height % 8
+    return rows
+
+
+def frame_rows_of_share(height: int, world: int, rank: int) -> torch.Tensor:
+    """Frame row of every row of rank's share, in the share's order."""
+    n = strip_rows(height, world, rank)
+    r = torch.arange(n, dtype=torch.int64)
+    return ((r // 8) * world + rank) * 8 + r % 8
+
+
+def assemble_strips(shares: Sequence[torch.Tensor], height: int) -> torch.Tensor:
+    """Puts the ranks' shares ([rows_k or more, width, ...] each; extra rows are padding) back into one frame."""
+    world = len(shares)
+    first = shares[0]
+    out = torch.empty((height,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+    for k, share in enumerate(shares):
+        rows = frame_rows_of_share(height, world, k).to(first.device)
+        out[rows] = share[:rows.numel()].to(first.device)
+    return out
+
+
+def gather_frame(share: torch.Tensor, height: int, rank: int, world: int, group=None) -> Optional[torch.Tensor]:
+    """Collective: every rank passes its share (strip_rows(height, world, rank) rows); rank 0 gets the frame.
+    Shares are padded to the longest one so that all ranks send the same shape."""
+    if world == 1:
+        return assemble_strips([share], height)
+    longest = strip_rows(height, world, 0)
+    send = share
+    if share.shape[0] != longest:
+        send = torch.zeros((longest,) + tuple(share.shape[1:]), dtype=share.dtype, device=share.device)
+        send[:share.shape[0]] = share
+    staged = send.is_cuda and dist.get_backend(group) == "gloo"      # gloo gathers host tensors only
+    if staged:
+        send = send.cpu()
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send.contiguous(), gather_list=recv, dst=0, group=group)
+    if rank != 0:
+        return None
+    return assemble_strips(recv, height)

@@ -24,6 +24,7 @@ def main():
     p.add_argument("--lights", type=int, default=2)
     p.add_argument("--frames", default="0,45")
     p.add_argument("--reps", type=int, default=3)
+    p.add_argument("--shares", default="2,4,8", help="also render the frame as N interleaved strip shares (what N GPUs would each do)")
     a = p.parse_args()
     from raytracer_amd import capi, demo, host_api as H
     dev = torch.device("cuda", 0)
@@ -51,8 +52,21 @@ def main():
             ms.append(ctx.last_kernel_ms())
         t = float(np.median(ms))
         rays = c["primary_rays"] + c["shadow_rays"]
-        rows.append({"frame": f, "ms": round(t, 3), "primary_rays": c["primary_rays"], "shadow_rays": c["shadow_rays"],
-                     "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1)})
+        row = {"frame": f, "ms": round(t, 3), "primary_rays": c["primary_rays"], "shadow_rays": c["shadow_rays"],
+               "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1)}
+        # one GPU renders every share in turn: the slowest share is the frame time of N GPUs before the gather
+        for n in [int(x) for x in a.shares.split(",") if x]:
+            per = []
+            for r in range(n):
+                part = torch.empty((max(capi.strip_rows(Hh, n, r), 1), W, 3), dtype=torch.uint8, device=dev)
+                ms = []
+                for _ in range(a.reps):
+                    ctx.render_sampled_strips(scene.camera, lights, tfs, W, Hh, a.spp, 0, n, r, part)
+                    ms.append(ctx.last_kernel_ms())
+                per.append(float(np.median(ms)))
+            row[f"shares_{n}"] = {"slowest_ms": round(max(per), 3), "fastest_ms": round(min(per), 3),
+                                  "speedup_before_gather": round(t / max(per), 2)}
+        rows.append(row)
     out = {"metric": "Mrays/s (primary+shadow), sampled frame", "unit": "Mrays/s",
            "value": round(float(np.mean([r["Mrays_per_s"] for r in rows])), 1),
            "config": {"workload": f"{W}x{Hh}, {a.spp} jittered camera rays per pixel, {a.lights} lights, drone/treasure/ground scene"},

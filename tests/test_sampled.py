@@ -126,8 +126,9 @@ def test_gpu_sampled_equals_restatement(gscene, po, meshes, spp, n_lights, size)
     cam, t, l = to_capi(capi, po, tfs, ls)
     rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
     hid = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
-    for block in (64, 256):
+    for block, split in ((64, 1), (256, 0), (64, 2), (64, 0)):
         gscene.set_option("block", block)
+        gscene.set_option("sampled_split", split)
         rgb.zero_()
         torch.cuda.synchronize()          # the fills above ran on torch's stream, the launches below use another one
         gscene.render_sampled(cam, l, t, w, h, spp, 99, rgb, hit_id=hid, flags=capi.RT_FLAG_COUNT_WORK)
@@ -138,6 +139,7 @@ def test_gpu_sampled_equals_restatement(gscene, po, meshes, spp, n_lights, size)
         for k in ("primary_rays", "shadow_rays", "hit_pixels", "shadowed_pixels"):
             assert c[k] == want.counters[k], k
     gscene.set_option("block", 64)
+    gscene.set_option("sampled_split", 1)
 
 
 @pytest.mark.gpu

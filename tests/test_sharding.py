@@ -7,6 +7,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import REPO
 
@@ -180,3 +181,53 @@ def test_frame_gather_single_rank_is_a_passthrough():
     g.submit(t)
     out = g.finish()
     assert len(out) == 1 and out[0][0] is t
+
+
+# ------------------------------------------------------------------ one frame over several ranks
+@pytest.mark.parametrize("height", [1, 7, 8, 9, 64, 135, 540, 1080])
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 200])
+def test_strip_shares_tile_the_frame(height, world):
+    """Every row of the frame belongs to exactly one rank's share, and the C library counts the same rows."""
+    from raytracer_amd import capi, sharding
+    seen = torch.zeros(height, dtype=torch.int64)
+    for r in range(world):
+        rows = sharding.frame_rows_of_share(height, world, r)
+        assert rows.numel() == sharding.strip_rows(height, world, r) == capi.strip_rows(height, world, r)
+        assert rows.numel() == 0 or (rows.max() < height and (rows[1:] > rows[:-1]).all())
+        seen[rows] += 1
+    assert (seen == 1).all()
+    frame = torch.arange(height * 5, dtype=torch.int32).reshape(height, 5)
+    shares = [frame[sharding.frame_rows_of_share(height, world, r)] for r in range(world)]
+    padded = [torch.cat([s, torch.full((3, 5), -1, dtype=torch.int32)]) for s in shares]          # padding rows are ignored
+    assert torch.equal(sharding.assemble_strips(padded, height), frame)
+
+
+def _gather_frame_worker(rank, world, port, height, q):
+    import torch.distributed as dist
+    from raytracer_amd import sharding
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    frame = (torch.arange(height * 4 * 3, dtype=torch.int64) % 251).to(torch.uint8).reshape(height, 4, 3)
+    share = frame[sharding.frame_rows_of_share(height, world, rank)].contiguous()        # what this rank would have rendered
+    got = sharding.gather_frame(share, height, rank, world)
+    if rank == 0:
+        q.put(bool(torch.equal(got, frame)))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height", [135, 13])
+def test_gather_frame_two_ranks_gloo(height):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_frame_worker, args=(r, 2, port, height, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
