@@ -114,7 +114,17 @@ def main():
             print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     from raytracer_amd import demo, sharding
-    scene = demo.DemoScene(local)
+    # create_mesh prints what it loaded on stdout, like the reference (mesh.c:112); stdout is kept for the
+    # one JSON line, so those lines go to stderr
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        scene = demo.DemoScene(local)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
     say("scene loaded")
     ctx = scene.ctx
     if a.block:

@@ -37,6 +37,7 @@ struct LdsStack {
     __device__ __forceinline__ void clear() { top = base; }
     __device__ __forceinline__ bool empty() const { return top == base; }
     __device__ __forceinline__ void push(uint32_t v) { *top = v; top += BLOCK; }
+    __device__ __forceinline__ void push_if(bool c, uint32_t v) { if (c) *top = v; top += c ? BLOCK : 0; }
     __device__ __forceinline__ uint32_t pop() { top -= BLOCK; return *top; }
 };
 

@@ -197,11 +197,11 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
                 slab_pair(sr, N, tl, tr, hl, hr);
                 if (CULL) { hl = hl && !(tl > q.limit); hr = hr && !(tr > q.limit); }
                 const bool left_first = !(tr < tl);
-                if (hl && hr) {
-                    stack.push(left_first ? N.rref : N.lref);
-                    ref = left_first ? N.lref : N.rref;
-                } else if (hl || hr) {
-                    ref = hl ? N.lref : N.rref;
+                const uint32_t nearer = left_first ? N.lref : N.rref, farther = left_first ? N.rref : N.lref;
+                const bool both = hl && hr;
+                stack.push_if(both, farther);
+                if (hl || hr) {
+                    ref = both ? nearer : (hl ? N.lref : N.rref);
                 } else if (stack.empty()) {
                     live = false;
                 } else {

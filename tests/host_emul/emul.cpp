@@ -24,6 +24,7 @@ struct ArrayStack {
     void clear() { sp = 0; }
     bool empty() const { return sp == 0; }
     void push(uint32_t v) { data[sp++] = v; if (sp > high) high = sp; }
+    void push_if(bool c, uint32_t v) { if (c) push(v); }
     uint32_t pop() { return data[--sp]; }
 };
 
