@@ -218,6 +218,11 @@ int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* l
                          const rt_transform* transforms, int32_t n_transforms,
                          int32_t width, int32_t height, uint32_t flags,
                          uint8_t* h_rgb, int32_t* h_hit_id, float* h_hit_t, uint8_t* h_shadow);
+/* Page-locked host memory for the host-buffer entry points: copies into it run at bus speed and do not
+ * fault pages in (Scene.frames of the host API library are allocated this way when a GPU is present).
+ * RT_ERR_NO_DEVICE without a GPU -- fall back to malloc. */
+int rt_pinned_alloc(size_t bytes, void** out);
+int rt_pinned_free(void* p);
 
 /* ---- encoder-side upscale -------------------------------------------------------------- */
 /* Output size save_scene derives from the scene (scene.c:164-165): (int)(size / scale_factor + 0.5f). */

@@ -58,7 +58,7 @@ NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left", "<i4"), 
                        ("start", "<i4"), ("count", "<i4")])     # rt_flat_node: 40 bytes
 
 EXPORTS = [
-    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_strip_rows", "rt_render_frame_strips", "rt_render_frame_sampled_strips", "rt_mesh_replace", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_stats", "rt_bvh_flatten_tree",
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_pinned_alloc", "rt_pinned_free", "rt_strip_rows", "rt_render_frame_strips", "rt_render_frame_sampled_strips", "rt_mesh_replace", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_stats", "rt_bvh_flatten_tree",
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
@@ -117,6 +117,8 @@ def lib():
         L.rt_render_frame_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, i32, i32,
                                               u32, u32, vp, vp, vp]
         L.rt_strip_rows.argtypes = [i32, i32, i32]
+        L.rt_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+        L.rt_pinned_free.argtypes = [vp]
         L.rt_render_frame_strips.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, i32, i32, u32,
                                              vp, vp, vp, vp, vp]
         L.rt_render_frame_sampled_strips.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, i32, i32,

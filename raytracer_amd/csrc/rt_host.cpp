@@ -767,11 +767,27 @@ int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* l
     st = rt_render_frame(ctx, camera, light, transforms, n_transforms, width, height, flags, ctx->d_rgb,
                          h_hit_id ? ctx->d_id : nullptr, h_hit_t ? ctx->d_t : nullptr, h_shadow ? ctx->d_shadow : nullptr, nullptr);
     if (st != RT_OK) return st;
+    // copies queued behind the kernel, one wait: with page-locked destinations (rt_pinned_alloc) they run at bus speed
+    RT_HIP(ctx, hipMemcpyAsync(h_rgb, ctx->d_rgb, pixels * 3, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_hit_id) RT_HIP(ctx, hipMemcpyAsync(h_hit_id, ctx->d_id, pixels * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (h_hit_t) RT_HIP(ctx, hipMemcpyAsync(h_hit_t, ctx->d_t, pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (h_shadow) RT_HIP(ctx, hipMemcpyAsync(h_shadow, ctx->d_shadow, pixels, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RT_HIP(ctx, hipMemcpy(h_rgb, ctx->d_rgb, pixels * 3, hipMemcpyDeviceToHost));
-    if (h_hit_id) RT_HIP(ctx, hipMemcpy(h_hit_id, ctx->d_id, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (h_hit_t) RT_HIP(ctx, hipMemcpy(h_hit_t, ctx->d_t, pixels * sizeof(float), hipMemcpyDeviceToHost));
-    if (h_shadow) RT_HIP(ctx, hipMemcpy(h_shadow, ctx->d_shadow, pixels, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_pinned_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return RT_ERR_NO_DEVICE; }
+    if (hipHostMalloc(out, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return RT_ERR_DEVICE; }
+    return RT_OK;
+}
+
+int rt_pinned_free(void* p) {
+    if (!p) return RT_OK;
+    if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return RT_ERR_DEVICE; }
     return RT_OK;
 }
 
@@ -787,8 +803,8 @@ int rt_render_frame_instanced_host(rt_ctx* ctx, const rt_camera* camera, const r
     st = rt_render_frame_instanced(ctx, camera, light, instances, n_instances, width, height, flags, ctx->d_rgb, nullptr, nullptr, nullptr,
                                    nullptr, nullptr);
     if (st != RT_OK) return st;
+    RT_HIP(ctx, hipMemcpyAsync(h_rgb, ctx->d_rgb, pixels * 3, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RT_HIP(ctx, hipMemcpy(h_rgb, ctx->d_rgb, pixels * 3, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -41,6 +41,7 @@ struct SceneState {
 };
 std::mutex g_lock;
 std::map<const void*, SceneState> g_states;
+std::map<const void*, void*> g_pinned_frames;    // Scene.frames array -> the page-locked block its frames live in
 int g_device = -1;
 
 int pick_device() {
@@ -349,7 +350,17 @@ Scene create_scene(int width, int height, int duration_ms, int fps, float scale_
     if (spx > px) px = spx;
     const int n = s.frame_count > 0 ? s.frame_count : 0;
     s.frames = (unsigned char**)calloc((size_t)n + 1, sizeof(unsigned char*));
-    for (int i = 0; i < n; i++) s.frames[i] = (unsigned char*)malloc(px * 3 + 1);
+    // With a GPU: one page-locked block for all frames (render_scene's copy back runs at bus speed and
+    // touches no fresh pages).  Otherwise, and if that fails, one malloc per frame like the reference.
+    const size_t each = (px * 3 + 1 + 63) & ~(size_t)63;
+    void* block = nullptr;
+    if (n > 0 && rt_pinned_alloc(each * (size_t)n, &block) == RT_OK) {
+        for (int i = 0; i < n; i++) s.frames[i] = (unsigned char*)block + each * (size_t)i;
+        std::lock_guard<std::mutex> g(g_lock);
+        g_pinned_frames[(const void*)s.frames] = block;
+    } else {
+        for (int i = 0; i < n; i++) s.frames[i] = (unsigned char*)malloc(px * 3 + 1);
+    }
     return s;
 }
 
@@ -414,7 +425,14 @@ void destroy_scene(Scene* scene) {                                              
     }
     free(scene->meshes);
     if (scene->frames) {
-        for (int i = 0; i < scene->frame_count; i++) free(scene->frames[i]);
+        void* block = nullptr;
+        {
+            std::lock_guard<std::mutex> g(g_lock);
+            auto it = g_pinned_frames.find((const void*)scene->frames);
+            if (it != g_pinned_frames.end()) { block = it->second; g_pinned_frames.erase(it); }
+        }
+        if (block) rt_pinned_free(block);
+        else for (int i = 0; i < scene->frame_count; i++) free(scene->frames[i]);
         free(scene->frames);
     }
     scene->meshes = nullptr; scene->frames = nullptr; scene->mesh_count = 0;
