@@ -450,6 +450,8 @@ int rt_scene_clear(rt_ctx* ctx) {
 
 int rt_mesh_count(const rt_ctx* ctx) { return ctx ? (int)ctx->meshes.size() : RT_ERR_INVALID; }
 
+}  // extern "C"
+
 namespace {
 
 // Rows of a frame `height` rows tall that belong to strips offset, offset + stride, ... (strips of eight rows).
@@ -565,6 +567,8 @@ int bad_strips(rt_ctx* ctx, int32_t stride, int32_t offset) {
 
 }  // namespace
 
+extern "C" {
+
 int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
                     int32_t n_transforms, int32_t width, int32_t height, uint32_t flags, void* d_rgb, void* d_hit_id,
                     void* d_hit_t, void* d_shadow, void* stream) {
@@ -626,6 +630,8 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light
     return RT_OK;
 }
 
+}  // extern "C"
+
 namespace {
 int render_sampled_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* lights, int32_t n_lights, const rt_transform* transforms,
                         int32_t n_transforms, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed, int32_t stride,
@@ -663,6 +669,8 @@ int render_sampled_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* li
     return RT_OK;
 }
 }  // namespace
+
+extern "C" {
 
 int rt_render_frame_sampled(rt_ctx* ctx, const rt_camera* camera, const rt_light* lights, int32_t n_lights, const rt_transform* transforms,
                             int32_t n_transforms, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed, uint32_t flags,
