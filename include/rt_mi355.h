@@ -124,6 +124,15 @@ int rt_mesh_upload_tree(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, co
  * structures allow it: rebuild with create_bvh / rt_bvh_build / rt_bvh_build_device, then call this).
  * Waits for frames in flight.  Device arrays are reused when the triangle count is unchanged. */
 int rt_mesh_replace(rt_ctx* ctx, int32_t mesh_id, const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes);
+/* The same two steps for a triangle soup in file order (what create_mesh has before it calls create_bvh,
+ * mesh.c:25-110): builds the reference's BVH -- on the GPU from "device_build_min" triangles up (rt_set_option,
+ * default 20 000), records for the kernels made there too, nothing but the nodes returns to the host -- and
+ * uploads (rt_mesh_upload_soup) or swaps it into an uploaded mesh (rt_mesh_rebuild, texture kept).  tris_out,
+ * if not NULL, receives the n_tris triangles in post-build order, the order reported triangle ids refer to.
+ * Results are those of rt_bvh_build + rt_mesh_upload / rt_mesh_replace. */
+int rt_mesh_upload_soup(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const uint8_t* h_rgba, int32_t tex_width, int32_t tex_height,
+                        int32_t* mesh_id, rt_triangle* tris_out);
+int rt_mesh_rebuild(rt_ctx* ctx, int32_t mesh_id, const rt_triangle* tris, int32_t n_tris, rt_triangle* tris_out);
 int rt_scene_clear(rt_ctx* ctx);                                  /* drops all meshes */
 int rt_mesh_count(const rt_ctx* ctx);
 
@@ -260,7 +269,7 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * handed to the cooperative pass), "resident_budget" (variants 5..9: bytes of small meshes staged in LDS),
  * "batch_chunk" (rt_render_frames: consecutive tiles of one frame before the same tiles of the next
  * frame; 0 = four tile rows), "xcd_swizzle" (rt_render_frames: 1 = each XCD gets runs of eight neighbouring
- * tiles, default; 0 = every eighth tile), "sampled_split" (rt_render_frame_sampled with four samples or
+ * tiles, default; 0 = every eighth tile), "device_build_min" (see rt_mesh_upload_soup), "sampled_split" (rt_render_frame_sampled with four samples or
  * more: the samples of a tile are traced by four waves and added up in order instead of one wave looping
  * over them -- 0 never, 1 when the launch has fewer than 100 000 tiles (default), 2 always).
  * Every setting produces the same image.  Read-only: "n_variants", "default_variant".

@@ -58,7 +58,7 @@ NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left", "<i4"), 
                        ("start", "<i4"), ("count", "<i4")])     # rt_flat_node: 40 bytes
 
 EXPORTS = [
-    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_pinned_alloc", "rt_pinned_free", "rt_strip_rows", "rt_render_frame_strips", "rt_render_frame_sampled_strips", "rt_mesh_replace", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_stats", "rt_bvh_flatten_tree",
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_status_string", "rt_pinned_alloc", "rt_pinned_free", "rt_strip_rows", "rt_render_frame_strips", "rt_render_frame_sampled_strips", "rt_mesh_replace", "rt_mesh_upload_soup", "rt_mesh_rebuild", "rt_bvh_build", "rt_bvh_build_device", "rt_bvh_build_stats", "rt_bvh_flatten_tree",
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
@@ -106,6 +106,8 @@ def lib():
         L.rt_mesh_upload.argtypes = [vp, vp, i32, vp, i32, vp, i32, i32, C.POINTER(i32)]
         L.rt_mesh_upload_tree.argtypes = [vp, vp, i32, vp, vp, i32, i32, C.POINTER(i32)]
         L.rt_mesh_replace.argtypes = [vp, i32, vp, i32, vp, i32]
+        L.rt_mesh_upload_soup.argtypes = [vp, vp, i32, vp, i32, i32, C.POINTER(i32), vp]
+        L.rt_mesh_rebuild.argtypes = [vp, i32, vp, i32, vp]
         L.rt_scene_clear.argtypes = [vp]
         L.rt_mesh_count.argtypes = [vp]
         L.rt_render_frame.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, u32,
@@ -232,6 +234,25 @@ class Context:
         nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
         assert tris.ndim == 2 and tris.shape[1] == TRI_FLOATS
         self._check(lib().rt_mesh_replace(self._h, int(mesh_id), tris.ctypes.data, int(tris.shape[0]), nodes.ctypes.data, int(nodes.shape[0])))
+
+    def upload_soup(self, tris: np.ndarray, rgba: np.ndarray, want_triangles: bool = False):
+        """rt_mesh_upload_soup: triangles in file order -> mesh id (and the triangles in post-build order if asked)."""
+        tris = np.ascontiguousarray(tris, dtype=np.float32)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        assert tris.ndim == 2 and tris.shape[1] == TRI_FLOATS and rgba.ndim == 3 and rgba.shape[2] == 4
+        out = np.empty_like(tris) if want_triangles else None
+        mid = C.c_int32(-1)
+        self._check(lib().rt_mesh_upload_soup(self._h, tris.ctypes.data, int(tris.shape[0]), rgba.ctypes.data, int(rgba.shape[1]),
+                                              int(rgba.shape[0]), C.byref(mid), out.ctypes.data if want_triangles else None))
+        return (mid.value, out) if want_triangles else mid.value
+
+    def rebuild_mesh(self, mesh_id: int, tris: np.ndarray, want_triangles: bool = False):
+        """rt_mesh_rebuild: new triangles (file order) for an uploaded mesh, BVH rebuilt; the texture stays."""
+        tris = np.ascontiguousarray(tris, dtype=np.float32)
+        assert tris.ndim == 2 and tris.shape[1] == TRI_FLOATS
+        out = np.empty_like(tris) if want_triangles else None
+        self._check(lib().rt_mesh_rebuild(self._h, int(mesh_id), tris.ctypes.data, int(tris.shape[0]), out.ctypes.data if want_triangles else None))
+        return out
 
     def upload_host_mesh(self, mesh) -> int:
         """Uploads a Mesh struct of raytracer_amd.host_api (what create_mesh returns) as it stands."""

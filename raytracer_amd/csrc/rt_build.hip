@@ -355,6 +355,71 @@ __global__ void k_gather(const float4* in, const int32_t* perm, int32_t n, float
     out[(int64_t)p * 6 + q] = in[(int64_t)perm[p] * 6 + q];
 }
 
+// ---- packing for the traversal kernels (what Packer in rt_pack.h does on the host) ---------------------
+// PairNodes are emitted in creation order of the internal nodes (node, left subtree, right subtree).
+__global__ void k_internal_sizes(const BfsNode* nodes, int32_t first, int32_t count, int32_t* isz, int32_t* max_leaf) {
+    const int32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const BfsNode& nd = nodes[first + i];
+    if (nd.left >= 0) isz[first + i] = 1 + isz[nd.left] + isz[nd.right];
+    else { isz[first + i] = 0; atomicMax(max_leaf, nd.count); }
+}
+
+__global__ void k_internal_number(const BfsNode* nodes, int32_t first, int32_t count, const int32_t* isz, int32_t* inum) {
+    const int32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const int32_t n = first + i;
+    const BfsNode& nd = nodes[n];
+    if (nd.left < 0) return;
+    const int32_t me = n == 0 ? 0 : inum[n];
+    if (n == 0) inum[0] = 0;
+    inum[nd.left] = me + 1;                              // only read if that child is internal
+    inum[nd.right] = me + 1 + isz[nd.left];
+}
+
+__global__ void k_pairs(const BfsNode* nodes, int32_t n_nodes, const int32_t* inum, PairNode* pairs) {
+    const int32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_nodes) return;
+    const BfsNode nd = nodes[n];
+    if (nd.left < 0) return;
+    const BfsNode l = nodes[nd.left], r = nodes[nd.right];
+    PairNode p;
+    for (int a = 0; a < 3; a++) { p.lmin[a] = l.bmin[a]; p.lmax[a] = l.bmax[a]; p.rmin[a] = r.bmin[a]; p.rmax[a] = r.bmax[a]; }
+    p.lref = l.left >= 0 ? (uint32_t)inum[nd.left] : leaf_ref((uint32_t)l.start, (uint32_t)l.count);
+    p.rref = r.left >= 0 ? (uint32_t)inum[nd.right] : leaf_ref((uint32_t)r.start, (uint32_t)r.count);
+    p.pad[0] = p.pad[1] = 0;
+    pairs[n == 0 ? 0 : inum[n]] = p;
+}
+
+// Tie order of the reference as a per-triangle priority: a later leaf beats an earlier one, inside a leaf
+// the lower index wins.  Leaves tile the triangle array in creation order, so the running count before a
+// leaf is its start.
+__global__ void k_leaf_prio(const BfsNode* nodes, int32_t n_nodes, uint32_t* prio) {
+    const int32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_nodes) return;
+    const BfsNode nd = nodes[n];
+    if (nd.left >= 0) return;
+    for (int32_t i = 0; i < nd.count; i++) prio[nd.start + i] = (uint32_t)(nd.start + (nd.count - i));
+}
+
+__global__ void k_records(const rt_triangle* tris, const uint32_t* prio, int32_t n, TriRec* tr, AttrRec* at) {
+    const int32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const rt_triangle s = tris[i];
+    TriRec t;
+    t.v0[0] = s.v0.x; t.v0[1] = s.v0.y; t.v0[2] = s.v0.z; t.prio = prio[i];
+    t.e1[0] = s.v1.x - s.v0.x; t.e1[1] = s.v1.y - s.v0.y; t.e1[2] = s.v1.z - s.v0.z; t.pad1 = 0.0f;      // ray.c:45-46
+    t.e2[0] = s.v2.x - s.v0.x; t.e2[1] = s.v2.y - s.v0.y; t.e2[2] = s.v2.z - s.v0.z; t.pad2 = 0.0f;
+    tr[i] = t;
+    AttrRec a;
+    a.t0[0] = s.t0.u; a.t0[1] = s.t0.v; a.t1[0] = s.t1.u; a.t1[1] = s.t1.v; a.t2[0] = s.t2.u; a.t2[1] = s.t2.v;
+    a.n0[0] = s.n0.x; a.n0[1] = s.n0.y; a.n0[2] = s.n0.z;
+    a.n1[0] = s.n1.x; a.n1[1] = s.n1.y; a.n1[2] = s.n1.z;
+    a.n2[0] = s.n2.x; a.n2[1] = s.n2.y; a.n2[2] = s.n2.z;
+    a.pad = 0.0f;
+    at[i] = a;
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 struct Arena {
     std::vector<void*> owned;
@@ -381,14 +446,30 @@ inline int blocks(int64_t items) { return (int)((items + kBlock - 1) / kBlock); 
 
 }  // namespace
 
-int build_bvh_on_device(rt_triangle* h_tris, int32_t n, rt_flat_node* h_nodes, int32_t cap, int32_t* n_nodes, hipStream_t stream,
-                        std::string& err, BuildStats* stats) {
-    if (stats) *stats = BuildStats();
+struct DeviceBvh::Impl {
+    std::string err;
     Arena A;
-    A.err = &err;
+    rt_triangle* d_in = nullptr; rt_triangle* d_out = nullptr;
+    BfsNode* nodes = nullptr; int32_t* size = nullptr; int32_t* number = nullptr; rt_flat_node* d_flat = nullptr;
+    int32_t* perm = nullptr;
+    std::vector<int32_t> level_first;      // first breadth-first node id of every level, then the node count
+    int32_t n = 0, total_nodes = 0;
+    bool flat_done = false;
+    Impl() { A.err = &err; }
+};
+
+DeviceBvh::~DeviceBvh() { delete impl; }
+
+int DeviceBvh::build(const rt_triangle* h_tris, int32_t n, hipStream_t stream, std::string& err) {
+    delete impl;
+    impl = new Impl;
+    Impl& I = *impl;
+    Arena& A = I.A;
+    stats = BuildStats();
+    I.n = n;
     const size_t N = (size_t)n;
-    rt_triangle* d_in = A.get<rt_triangle>(N);
-    rt_triangle* d_out = A.get<rt_triangle>(N);
+    rt_triangle* d_in = I.d_in = A.get<rt_triangle>(N);
+    I.d_out = A.get<rt_triangle>(N);
     float4* keys = A.get<float4>(N);
     float4* box = A.get<float4>(2 * N);
     float* kk = A.get<float>(N);
@@ -403,15 +484,15 @@ int build_bvh_on_device(rt_triangle* h_tris, int32_t n, rt_flat_node* h_nodes, i
     float* split = A.get<float>(N);
     int32_t* child = A.get<int32_t>(N);
     int32_t* lead = A.get<int32_t>(N);
-    BfsNode* nodes = A.get<BfsNode>(2 * N);
-    int32_t* size = A.get<int32_t>(2 * N);
-    int32_t* number = A.get<int32_t>(2 * N);
-    rt_flat_node* d_flat = A.get<rt_flat_node>(2 * N);
+    BfsNode* nodes = I.nodes = A.get<BfsNode>(2 * N);
+    I.size = A.get<int32_t>(2 * N);
+    I.number = A.get<int32_t>(2 * N);
+    I.d_flat = A.get<rt_flat_node>(2 * N);
     LevelCounters* d_cnt = A.get<LevelCounters>(1);
     size_t scan_bytes = 0;
     if (A.ok) BUILD_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, less, lsum, 0u, N + 1, rocprim::plus<uint32_t>(), stream));
     uint8_t* scan_tmp = A.get<uint8_t>(scan_bytes);
-    if (!A.ok) return RT_ERR_DEVICE;
+    if (!A.ok) { err = I.err; return RT_ERR_DEVICE; }
     LevelCounters* h_cnt = nullptr;
     BUILD_HIP(hipHostMalloc((void**)&h_cnt, sizeof(LevelCounters)));
     struct Pinned { LevelCounters* p; ~Pinned() { (void)hipHostFree(p); } } pinned{h_cnt};
@@ -430,7 +511,8 @@ int build_bvh_on_device(rt_triangle* h_tris, int32_t n, rt_flat_node* h_nodes, i
     BUILD_HIP(hipMemcpyAsync(d_cnt, h_cnt, sizeof(LevelCounters), hipMemcpyHostToDevice, stream));
     BUILD_HIP(hipStreamSynchronize(stream));             // `root` and *h_cnt are reused below
 
-    std::vector<int32_t> level_first{0};                 // first breadth-first node id of every level
+    std::vector<int32_t>& level_first = I.level_first;
+    level_first.assign(1, 0);
     int32_t nseg = 1, max_count = n, total_nodes = 1;
     int cur = 0, levels = 0, launches = 0;
     while (nseg > 0) {
@@ -471,33 +553,122 @@ int build_bvh_on_device(rt_triangle* h_tris, int32_t n, rt_flat_node* h_nodes, i
         }
     }
     BUILD_HIP(hipGetLastError());
-    if (total_nodes > cap) { err = "node array too small"; return RT_ERR_CAPACITY; }
     if (level_first.back() == total_nodes) level_first.pop_back();            // the last round created nothing
     level_first.push_back(total_nodes);
-    const int n_levels = (int)level_first.size() - 1;
-    for (int l = n_levels - 1; l >= 0; l--) {
-        const int32_t c = level_first[l + 1] - level_first[l];
-        hipLaunchKernelGGL(k_sizes, dim3(blocks(c)), dim3(kBlock), 0, stream, nodes, level_first[l], c, size);
-    }
-    for (int l = 0; l < n_levels; l++) {
-        const int32_t c = level_first[l + 1] - level_first[l];
-        hipLaunchKernelGGL(k_number, dim3(blocks(c)), dim3(kBlock), 0, stream, nodes, level_first[l], c, size, number);
-    }
-    hipLaunchKernelGGL(k_emit, dim3(blocks(total_nodes)), dim3(kBlock), 0, stream, nodes, total_nodes, number, d_flat);
-    hipLaunchKernelGGL(k_gather, dim3(blocks((int64_t)n * 6)), dim3(kBlock), 0, stream, (const float4*)d_in, perm[cur], n, (float4*)d_out);
-    launches += 2 * n_levels + 2;
+    I.total_nodes = total_nodes;
+    I.perm = perm[cur];
+    hipLaunchKernelGGL(k_gather, dim3(blocks((int64_t)n * 6)), dim3(kBlock), 0, stream, (const float4*)d_in, I.perm, n, (float4*)I.d_out);
+    launches += 1;
     BUILD_HIP(hipEventRecord(ev1, stream));
-    BUILD_HIP(hipMemcpyAsync(h_nodes, d_flat, (size_t)total_nodes * sizeof(rt_flat_node), hipMemcpyDeviceToHost, stream));
-    BUILD_HIP(hipMemcpyAsync(h_tris, d_out, N * sizeof(rt_triangle), hipMemcpyDeviceToHost, stream));
     BUILD_HIP(hipStreamSynchronize(stream));
     BUILD_HIP(hipGetLastError());
-    *n_nodes = total_nodes;
-    if (stats) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) stats->device_ms = ms;
-        stats->levels = n_levels; stats->launches = launches; stats->nodes = total_nodes;
-    }
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) stats.device_ms = ms;
+    stats.levels = (int)level_first.size() - 1; stats.launches = launches; stats.nodes = total_nodes;
     return RT_OK;
+}
+
+// Flat node array in creation order + the triangles in post-build order, to the host.
+int DeviceBvh::download(rt_triangle* h_tris, rt_flat_node* h_nodes, int32_t cap, int32_t* n_nodes, hipStream_t stream, std::string& err) {
+    if (!impl) { err = "no build"; return RT_ERR_INVALID; }
+    Impl& I = *impl;
+    if (I.total_nodes > cap) { err = "node array too small"; return RT_ERR_CAPACITY; }
+    const int n_levels = (int)I.level_first.size() - 1;
+    for (int l = n_levels - 1; l >= 0; l--) {
+        const int32_t c = I.level_first[l + 1] - I.level_first[l];
+        hipLaunchKernelGGL(k_sizes, dim3(blocks(c)), dim3(kBlock), 0, stream, I.nodes, I.level_first[l], c, I.size);
+    }
+    for (int l = 0; l < n_levels; l++) {
+        const int32_t c = I.level_first[l + 1] - I.level_first[l];
+        hipLaunchKernelGGL(k_number, dim3(blocks(c)), dim3(kBlock), 0, stream, I.nodes, I.level_first[l], c, I.size, I.number);
+    }
+    hipLaunchKernelGGL(k_emit, dim3(blocks(I.total_nodes)), dim3(kBlock), 0, stream, I.nodes, I.total_nodes, I.number, I.d_flat);
+    stats.launches += 2 * n_levels + 1;
+    BUILD_HIP(hipMemcpyAsync(h_nodes, I.d_flat, (size_t)I.total_nodes * sizeof(rt_flat_node), hipMemcpyDeviceToHost, stream));
+    if (h_tris) BUILD_HIP(hipMemcpyAsync(h_tris, I.d_out, (size_t)I.n * sizeof(rt_triangle), hipMemcpyDeviceToHost, stream));
+    BUILD_HIP(hipStreamSynchronize(stream));
+    BUILD_HIP(hipGetLastError());
+    *n_nodes = I.total_nodes;
+    return RT_OK;
+}
+
+int DeviceBvh::triangles_to_host(rt_triangle* h_tris, hipStream_t stream, std::string& err) {
+    if (!impl) { err = "no build"; return RT_ERR_INVALID; }
+    BUILD_HIP(hipMemcpyAsync(h_tris, impl->d_out, (size_t)impl->n * sizeof(rt_triangle), hipMemcpyDeviceToHost, stream));
+    BUILD_HIP(hipStreamSynchronize(stream));
+    return RT_OK;
+}
+
+// The records the traversal kernels read, made where the tree is.  d_tris / d_attrs are new device arrays
+// owned by the caller; pairs come back to the host (the scene's combined node array is assembled there).
+// RT_ERR_UNSUPPORTED (nothing allocated) when a leaf has more triangles than one leaf reference holds or
+// the tree is deeper than the traversal stack: the host packer handles or reports those.
+int DeviceBvh::pack(PackedOnDevice& out, hipStream_t stream, std::string& err) {
+    if (!impl) { err = "no build"; return RT_ERR_INVALID; }
+    Impl& I = *impl;
+    const int n_levels = (int)I.level_first.size() - 1;
+    if (n_levels - 1 > RT_MAX_TREE_DEPTH || n_levels + 1 > kStackDepth) { err = "BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
+    Arena tmp;
+    tmp.err = &err;
+    int32_t* isz = tmp.get<int32_t>((size_t)I.total_nodes);
+    int32_t* inum = tmp.get<int32_t>((size_t)I.total_nodes);
+    uint32_t* prio = tmp.get<uint32_t>((size_t)I.n);
+    int32_t* max_leaf = tmp.get<int32_t>(1);
+    if (!tmp.ok) return RT_ERR_DEVICE;
+    BUILD_HIP(hipMemsetAsync(max_leaf, 0, sizeof(int32_t), stream));
+    for (int l = n_levels - 1; l >= 0; l--) {
+        const int32_t c = I.level_first[l + 1] - I.level_first[l];
+        hipLaunchKernelGGL(k_internal_sizes, dim3(blocks(c)), dim3(kBlock), 0, stream, I.nodes, I.level_first[l], c, isz, max_leaf);
+    }
+    int32_t h_info[2] = {0, 0};
+    BUILD_HIP(hipMemcpyAsync(&h_info[0], max_leaf, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    BUILD_HIP(hipMemcpyAsync(&h_info[1], isz, sizeof(int32_t), hipMemcpyDeviceToHost, stream));      // internal nodes of the whole tree
+    BUILD_HIP(hipStreamSynchronize(stream));
+    if (h_info[0] > kMaxLeafTris) { err = "a leaf holds more triangles than one leaf reference"; return RT_ERR_UNSUPPORTED; }
+    const int32_t n_pairs = h_info[1];
+    for (int l = 0; l < n_levels; l++) {
+        const int32_t c = I.level_first[l + 1] - I.level_first[l];
+        hipLaunchKernelGGL(k_internal_number, dim3(blocks(c)), dim3(kBlock), 0, stream, I.nodes, I.level_first[l], c, isz, inum);
+    }
+    PairNode* d_pairs = tmp.get<PairNode>((size_t)n_pairs);
+    TriRec* d_tris = nullptr; AttrRec* d_attrs = nullptr;
+    if (!tmp.ok) return RT_ERR_DEVICE;
+    if (hipMalloc((void**)&d_tris, (size_t)I.n * sizeof(TriRec)) != hipSuccess || hipMalloc((void**)&d_attrs, (size_t)I.n * sizeof(AttrRec)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_tris) (void)hipFree(d_tris);
+        err = "hipMalloc of the packed mesh failed";
+        return RT_ERR_DEVICE;
+    }
+    hipLaunchKernelGGL(k_pairs, dim3(blocks(I.total_nodes)), dim3(kBlock), 0, stream, I.nodes, I.total_nodes, inum, d_pairs);
+    hipLaunchKernelGGL(k_leaf_prio, dim3(blocks(I.total_nodes)), dim3(kBlock), 0, stream, I.nodes, I.total_nodes, prio);
+    hipLaunchKernelGGL(k_records, dim3(blocks(I.n)), dim3(kBlock), 0, stream, I.d_out, prio, I.n, d_tris, d_attrs);
+    out.pairs.resize((size_t)n_pairs);
+    BfsNode root;
+    hipError_t e = hipMemcpyAsync(&root, I.nodes, sizeof(BfsNode), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && n_pairs > 0) e = hipMemcpyAsync(out.pairs.data(), d_pairs, (size_t)n_pairs * sizeof(PairNode), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        (void)hipFree(d_tris); (void)hipFree(d_attrs);
+        err = std::string("device packing: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return RT_ERR_DEVICE;
+    }
+    out.d_tris = d_tris; out.d_attrs = d_attrs;
+    memcpy(out.root_min, root.bmin, 12); memcpy(out.root_max, root.bmax, 12);
+    out.root_ref = root.left >= 0 ? 0u : leaf_ref(0u, (uint32_t)root.count);
+    out.depth = n_levels - 1;
+    return RT_OK;
+}
+
+int build_bvh_on_device(rt_triangle* h_tris, int32_t n, rt_flat_node* h_nodes, int32_t cap, int32_t* n_nodes, hipStream_t stream,
+                        std::string& err, BuildStats* stats) {
+    if (stats) *stats = BuildStats();
+    DeviceBvh b;
+    int rc = b.build(h_tris, n, stream, err);
+    if (rc == RT_OK) rc = b.download(h_tris, h_nodes, cap, n_nodes, stream, err);
+    if (stats) *stats = b.stats;
+    return rc;
 }
 
 }  // namespace rt

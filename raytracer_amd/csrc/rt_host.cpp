@@ -7,6 +7,7 @@
 
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rt_build.h"
@@ -22,7 +23,8 @@ constexpr int kInstSlots = 2;
 
 struct DeviceMesh {
     std::vector<PairNode> pairs;   // host copy; the device copy lives in the scene's combined array
-    std::vector<TriRec> tris;      // host copy, for the LDS-resident blob
+    std::vector<TriRec> tris;      // host copy, for the LDS-resident blob (empty for a mesh packed on the device)
+    bool host_tris = true;
     int depth = 0;
     TriRec* d_tris = nullptr;
     AttrRec* d_attrs = nullptr;
@@ -81,6 +83,7 @@ struct rt_ctx {
     hipEvent_t batch_done[kBatchSlots] = {};
     bool batch_used[kBatchSlots] = {};
     unsigned batch_seq = 0;
+    int device_build_min = 20000;  // triangle count from which rt_mesh_upload_soup / rt_mesh_rebuild build on the device
     int sampled_split = 1;         // sampled frames: the samples of a tile spread over four waves
     float build_ms = 0.0f;         // last rt_bvh_build_device
     int build_levels = 0, build_launches = 0;
@@ -140,7 +143,7 @@ int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tr
         if (dm.d_attrs) (void)hipFree(dm.d_attrs);
         dm.d_tris = t; dm.d_attrs = a;
     }
-    dm.pairs = pk.pairs; dm.tris = pk.tris; dm.depth = pk.depth;
+    dm.pairs = pk.pairs; dm.tris = pk.tris; dm.depth = pk.depth; dm.host_tris = true;
     dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs;
     memcpy(dm.proto.root_min, pk.root_min, 12);
     memcpy(dm.proto.root_max, pk.root_max, 12);
@@ -148,6 +151,50 @@ int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tr
     dm.proto.empty = pk.empty ? 1u : 0u;
     dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.pairs.size();
     return RT_OK;
+}
+
+// Triangles in file order -> BVH and packed records in dm.  Large soups are built and packed on the device
+// (rt_build.hip) and only the nodes come back; small ones, and trees the device packer leaves to the host
+// (a leaf too large for one leaf reference), go through rt_bvh_build + Packer.  tris_out, if given, receives
+// the triangles in post-build order (the order triangle ids refer to).
+int build_into(rt_ctx* ctx, DeviceMesh& dm, const rt_triangle* tris, int32_t n, rt_triangle* tris_out) {
+    std::string why;
+    if (n >= ctx->device_build_min && n > 0) {
+        DeviceBvh bvh;
+        int st = bvh.build(tris, n, ctx->stream, why);
+        if (st != RT_OK) return fail(ctx, st, why);
+        ctx->build_ms = bvh.stats.device_ms; ctx->build_levels = bvh.stats.levels; ctx->build_launches = bvh.stats.launches;
+        PackedOnDevice pk;
+        st = bvh.pack(pk, ctx->stream, why);
+        if (st == RT_OK) {
+            if (tris_out) { st = bvh.triangles_to_host(tris_out, ctx->stream, why); if (st != RT_OK) { (void)hipFree(pk.d_tris); (void)hipFree(pk.d_attrs); return fail(ctx, st, why); } }
+            if (pk.pairs.size() >= (size_t)kLeafBit) { (void)hipFree(pk.d_tris); (void)hipFree(pk.d_attrs); return fail(ctx, RT_ERR_UNSUPPORTED, "too many internal nodes"); }
+            if (dm.d_tris) (void)hipFree(dm.d_tris);
+            if (dm.d_attrs) (void)hipFree(dm.d_attrs);
+            dm.d_tris = pk.d_tris; dm.d_attrs = pk.d_attrs;
+            dm.pairs.swap(pk.pairs); dm.tris.clear(); dm.tris.shrink_to_fit(); dm.host_tris = false; dm.depth = pk.depth;
+            dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs;
+            memcpy(dm.proto.root_min, pk.root_min, 12);
+            memcpy(dm.proto.root_max, pk.root_max, 12);
+            dm.proto.root_ref = pk.root_ref;
+            dm.proto.empty = 0u;
+            dm.n_tris = n; dm.n_pairs = (int32_t)dm.pairs.size();
+            return RT_OK;
+        }
+        if (st != RT_ERR_UNSUPPORTED) return fail(ctx, st, why);
+        // fall through: the host packer splits oversize leaves, or says why the tree cannot be used
+    }
+    std::vector<rt_triangle> post(tris, tris + (n > 0 ? n : 0));
+    std::vector<rt_flat_node> nodes((size_t)2 * (size_t)(n > 0 ? n : 1) + 1);
+    int32_t used = 0;
+    int st = rt_bvh_build(post.data(), n, nodes.data(), (int32_t)nodes.size(), &used);
+    if (st != RT_OK) return fail(ctx, st, "BVH build failed");
+    PackedMesh pk;
+    st = Packer(post.data(), n, nodes.data(), used, pk).run(why);
+    if (st != RT_OK) return fail(ctx, st, why);
+    st = set_geometry(ctx, dm, pk, n);
+    if (st == RT_OK && tris_out && n > 0) memcpy(tris_out, post.data(), (size_t)n * sizeof(rt_triangle));
+    return st;
 }
 
 // Rebuilds the combined node array after the mesh list changed.
@@ -179,7 +226,7 @@ int commit_scene(rt_ctx* ctx) {
     for (auto& m : ctx->meshes) { m.proto.res_pairs = kNotResident; m.proto.res_tris = kNotResident; }
     for (size_t k : order) {
         DeviceMesh& m = ctx->meshes[k];
-        if (m.proto.empty || blob.size() + bytes_of(k) > (size_t)ctx->resident_budget) continue;
+        if (m.proto.empty || !m.host_tris || blob.size() + bytes_of(k) > (size_t)ctx->resident_budget) continue;
         m.proto.res_pairs = (uint32_t)blob.size();
         blob.insert(blob.end(), (const uint8_t*)m.pairs.data(), (const uint8_t*)(m.pairs.data() + m.pairs.size()));
         m.proto.res_tris = (uint32_t)blob.size();
@@ -408,7 +455,7 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const r
     if (st != RT_OK) { free_mesh(dm); return st; }
     dm.proto.texels = dm.d_texels;
     dm.proto.tex_w = tex_width; dm.proto.tex_h = tex_height;
-    ctx->meshes.push_back(dm);
+    ctx->meshes.push_back(std::move(dm));
     ctx->scene_dirty = true;
     if (mesh_id) *mesh_id = (int32_t)ctx->meshes.size() - 1;
     return RT_OK;
@@ -424,6 +471,45 @@ int rt_mesh_replace(rt_ctx* ctx, int32_t mesh_id, const rt_triangle* tris, int32
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipDeviceSynchronize());                 // frames in flight still read the old arrays
     st = set_geometry(ctx, ctx->meshes[(size_t)mesh_id], pk, n_tris);
+    ctx->scene_dirty = true;
+    return st;
+}
+
+int rt_mesh_upload_soup(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const uint8_t* h_rgba, int32_t tex_width, int32_t tex_height,
+                        int32_t* mesh_id, rt_triangle* tris_out) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (n_tris < 0 || (n_tris > 0 && !tris)) return fail(ctx, RT_ERR_INVALID, "null or negative triangle array");
+    if (n_tris > RT_MAX_MESH_TRIS) return fail(ctx, RT_ERR_UNSUPPORTED, "too many triangles in one mesh");
+    if (!h_rgba || tex_width <= 0 || tex_height <= 0) return fail(ctx, RT_ERR_INVALID, "texture missing or empty");
+    if ((int64_t)tex_width * tex_height > (int64_t)1 << 28) return fail(ctx, RT_ERR_UNSUPPORTED, "texture too large");
+    if ((int)ctx->meshes.size() >= RT_MAX_GEOMETRIES) return fail(ctx, RT_ERR_UNSUPPORTED, "too many meshes uploaded");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceMesh dm;
+    memset(&dm.proto, 0, sizeof(dm.proto));
+    int st = build_into(ctx, dm, tris, n_tris, tris_out);
+    if (st == RT_OK) {
+        const size_t bytes = (size_t)tex_width * (size_t)tex_height * 4;
+        hipError_t e = hipMalloc((void**)&dm.d_texels, bytes);
+        if (e == hipSuccess) e = hipMemcpy(dm.d_texels, h_rgba, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) st = hip_fail(ctx, e, "texture upload");
+    }
+    if (st != RT_OK) { free_mesh(dm); return st; }
+    dm.proto.texels = dm.d_texels;
+    dm.proto.tex_w = tex_width; dm.proto.tex_h = tex_height;
+    ctx->meshes.push_back(std::move(dm));
+    ctx->scene_dirty = true;
+    if (mesh_id) *mesh_id = (int32_t)ctx->meshes.size() - 1;
+    return RT_OK;
+}
+
+int rt_mesh_rebuild(rt_ctx* ctx, int32_t mesh_id, const rt_triangle* tris, int32_t n_tris, rt_triangle* tris_out) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (mesh_id < 0 || mesh_id >= (int32_t)ctx->meshes.size()) return fail(ctx, RT_ERR_INVALID, "no such mesh");
+    if (n_tris < 0 || (n_tris > 0 && !tris)) return fail(ctx, RT_ERR_INVALID, "null or negative triangle array");
+    if (n_tris > RT_MAX_MESH_TRIS) return fail(ctx, RT_ERR_UNSUPPORTED, "too many triangles in one mesh");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipDeviceSynchronize());                 // frames in flight still read the old arrays
+    const int st = build_into(ctx, ctx->meshes[(size_t)mesh_id], tris, n_tris, tris_out);
     ctx->scene_dirty = true;
     return st;
 }
@@ -918,6 +1004,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "coop")) { ctx->coop = value; return RT_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "sampled_split")) { ctx->sampled_split = value < 0 ? 0 : (value > 2 ? 2 : value); return RT_OK; }
+    if (!strcmp(name, "device_build_min")) { ctx->device_build_min = value < 1 ? 1 : value; return RT_OK; }
     if (!strcmp(name, "batch_chunk")) {
         if (value < 0 || value > (1 << 20)) return fail(ctx, RT_ERR_INVALID, "batch_chunk out of range");
         ctx->batch_chunk = value; return RT_OK;
@@ -939,6 +1026,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "block")) { *value = ctx->cfg.block; return RT_OK; }
     if (!strcmp(name, "timing")) { *value = ctx->timing; return RT_OK; }
     if (!strcmp(name, "sampled_split")) { *value = ctx->sampled_split; return RT_OK; }
+    if (!strcmp(name, "device_build_min")) { *value = ctx->device_build_min; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }
     if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }

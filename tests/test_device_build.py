@@ -172,3 +172,71 @@ def test_mesh_rebuilt_every_frame_renders_like_the_reference_loop(capi, ctx, po)
     L = capi.lib()
     assert L.rt_mesh_replace(c._h, 7, tris.ctypes.data, 100, nodes.ctypes.data, int(nodes.shape[0])) == capi.RT_ERR_INVALID
     c.close()
+
+
+@pytest.mark.parametrize("threshold", [1, 1 << 30])
+def test_upload_soup_renders_the_golden_frames(capi, po, golden_hashes, threshold):
+    """rt_mesh_upload_soup: file-order triangles in, BVH built and packed on the device (threshold 1) or on the
+    host (threshold above every mesh): same triangle order back, same frames as the golden hashes."""
+    import hashlib
+    import torch
+    c = capi.Context(0)
+    c.set_option("device_build_min", threshold)
+    meshes = po.default_meshes()
+    for name, m in zip(NAMES, meshes):
+        soup = po.load_obj(os.path.join(po.ASSETS, name + ".obj"))
+        mid, post = c.upload_soup(soup, m.rgba, want_triangles=True)
+        assert np.array_equal(post.view(np.uint32), np.ascontiguousarray(m.tris, np.float32).view(np.uint32))
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    pl = po.default_light()
+    light = capi.Light(capi.Vec3(*pl.direction.tup()), capi.Vec3(*pl.color.tup()))
+    w, h = 720, 540
+    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    hid = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+    for f in (0, 45, 95):
+        tfs = [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in po.animation_transforms(f)]
+        for variant in (0, 3):
+            c.set_option("variant", variant)
+            c.render(cam, light, tfs, w, h, rgb, hit_id=hid)
+            c.sync()
+            assert hashlib.sha256(rgb.cpu().numpy().tobytes()).hexdigest() == golden_hashes["frames"][f"{w}x{h}_f{f}"]["rgb"]
+            assert hashlib.sha256(hid.cpu().numpy().tobytes()).hexdigest() == golden_hashes["frames"][f"{w}x{h}_f{f}"]["hit_id"]
+    c.close()
+
+
+def test_upload_soup_edge_cases_and_rebuild(capi, po):
+    """Device path with a leaf too large for one reference (falls back to the host packer), a tiny soup, an empty
+    one; rt_mesh_rebuild on the device path against the oracle."""
+    import torch
+    meshes = po.default_meshes()
+    c = capi.Context(0)
+    c.set_option("device_build_min", 1)
+    one = soup_of(1, 7)
+    big_leaf = np.concatenate([np.repeat(one, 300, axis=0), soup_of(500, 9)])
+    drone_soup = po.load_obj(os.path.join(po.ASSETS, "drone.obj"))
+    ids = [c.upload_soup(drone_soup, meshes[0].rgba), c.upload_soup(big_leaf, meshes[1].rgba), c.upload_soup(soup_of(3, 2), meshes[2].rgba),
+           c.upload_soup(np.zeros((0, 24), np.float32), meshes[2].rgba)]
+    assert ids == [0, 1, 2, 3]
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    pl = po.default_light()
+    light = capi.Light(capi.Vec3(*pl.direction.tup()), capi.Vec3(*pl.color.tup()))
+    w, h = 160, 90
+    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    hid = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+    soups = [drone_soup, big_leaf, soup_of(3, 2), np.zeros((0, 24), np.float32)]
+    texs = [meshes[0].rgba, meshes[1].rgba, meshes[2].rgba, meshes[2].rgba]
+    for frame in (0, 20):
+        if frame:
+            soups[0] = bake(drone_soup, 0.1 * frame, (1.0, 1.0, -0.5))
+            post = c.rebuild_mesh(0, soups[0], want_triangles=True)
+            assert np.array_equal(post.view(np.uint32), po.build_bvh(soups[0])[0].view(np.uint32))
+        ref = [po.HostMesh(*po.build_bvh(s), t) for s, t in zip(soups, texs)]
+        ptfs = [po.Transform(po.vec3(0, 0.2, 0), po.vec3(0, 0.3, 0)), po.Transform(po.vec3(-4, 0, 2), po.vec3(0, 0, 0)),
+                po.Transform(po.vec3(-3, 0, -2), po.vec3(0.2, 0, 0)), po.Transform()]
+        tfs = [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in ptfs]
+        c.render(cam, light, tfs, w, h, rgb, hit_id=hid)
+        c.sync()
+        want = po.render_frame(ref, ptfs, po.default_camera(), po.default_light(), w, h)
+        assert np.array_equal(hid.cpu().numpy(), want.hit_id) and np.array_equal(rgb.cpu().numpy(), want.rgb)
+        assert len(set(np.unique(want.hit_id[want.hit_id >= 0] >> 24).tolist())) >= 2
+    c.close()
