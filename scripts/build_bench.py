@@ -47,6 +47,17 @@ def main():
         st = ctx.build_stats()
         row = {"triangles": n, "nodes": int(got_n.shape[0]), "levels": st["levels"], "launches": st["launches"],
                "device_kernels_ms": round(float(np.median(dev_kernels)), 2), "device_call_ms": round(1e3 * float(np.median(dev_wall)), 1)}
+        # triangles in file order -> mesh ready to render (build + packing on the device, nodes back to the host)
+        tex = np.zeros((2, 2, 4), np.uint8)
+        ctx.set_option("device_build_min", 1)
+        mid = ctx.upload_soup(soup, tex)
+        t_re = []
+        for _ in range(a.reps):
+            t0 = time.perf_counter()
+            ctx.rebuild_mesh(mid, soup)
+            t_re.append(time.perf_counter() - t0)
+        row["rt_mesh_rebuild_ms"] = round(1e3 * float(np.median(t_re)), 1)
+        capi.lib().rt_scene_clear(ctx._h)
         if not a.no_host:
             t0 = time.perf_counter()
             want_t, want_n = capi.build_bvh(soup)
