@@ -205,6 +205,27 @@ def main():
     else:
         dt_all, rays_all = dt, float(rays_rank)
 
+    # ---- untimed: what arrives on rank 0 is what the ranks rendered.  Every rank sends the first batch of its
+    # share once more; rank 0 renders the same frames itself and compares the bytes.
+    gather_ok = None
+    if world > 1:
+        def first_batch(r):
+            sh = sharding.frames_for_rank(NF, r, world) or [r % NF]
+            return [sh[i % len(sh)] for i in range(a.batch)]
+        scene.render_frames(first_batch(rank), W, H, bufs[0], stream=sptr)
+        g = sharding.FrameGather(rank, world)
+        g.submit(bufs[0])
+        got = g.finish()
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            mine = torch.empty_like(bufs[0])
+            gather_ok = True
+            for r in range(world):
+                scene.render_frames(first_batch(r), W, H, mine, stream=sptr)
+                stream.synchronize()
+                gather_ok = gather_ok and bool(torch.equal(mine, got[0][r].to(dev)))
+        say(f"gather verified: {gather_ok}")
+
     # ---- kernel duration with HIP events on the launch stream (rank 0): the same launches as the
     # timed region, one at a time
     roof, single_ms = None, None
@@ -270,7 +291,8 @@ def main():
             "dtype": "f32", "data": "reference scene assets (drone/treasure/ground OBJ + WebP), animation frames of raytracer.c",
             "config": {"workload": f"{W}x{H} frame, 1 primary ray/pixel + 1 shadow ray/hit pixel, 3 meshes (3625 triangles)",
                        "frames_per_rank": a.steps, "frames_per_launch": a.batch, "sharding": "frame f on rank f mod N" if world > 1 else "single GPU",
-                       "gather": f"RGB8 framebuffers to rank 0 over RCCL, {a.batch} frames per message" if world > 1 else "none"},
+                       "gather": f"RGB8 framebuffers to rank 0 over RCCL, {a.batch} frames per message" if world > 1 else "none",
+                       "gathered_frames_equal_rank0_render": gather_ok},
             "frames_per_s": round(a.steps * world / dt_all, 2),
             "rays_per_frame": int(rays_rank / a.steps),
             "single_frame_kernel_ms": single_ms,
