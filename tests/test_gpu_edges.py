@@ -129,3 +129,40 @@ def test_strip_shares_equal_the_whole_frame(capi, po, meshes, size):
     with pytest.raises(capi.RtError):
         c.render_sampled_strips(cam, [light], tfs, w, h, 2, 0, 3, -1, full["rgb"])
     c.close()
+
+
+def test_limits_eight_meshes_and_sixteen_frames(capi, po, meshes):
+    """The plain paths at their limits: RT_MAX_MESHES meshes in one scene, RT_MAX_BATCH frames in one launch;
+    one mesh more is refused with a pointer to the instanced path."""
+    import torch
+    c = capi.Context(0)
+    parts, tfs = [], []
+    rng = np.random.default_rng(4)
+    for k in range(capi.RT_MAX_MESHES):
+        m = meshes[k % 3]
+        parts.append(m)
+        c.upload_mesh(m.tris, m.nodes, m.rgba)
+        tfs.append(po.Transform(po.vec3(*(rng.uniform(-2, 2, 3) * [1, 0.3, 1] + [0, 0.6, 0])), po.vec3(0, float(rng.uniform(0, 6)), 0)) if k % 3 != 2
+                   else po.Transform(po.vec3(0, -0.2 * (k // 3), 0), po.vec3(0, 0, 0)))
+    cam, light = camera_light(capi, po)
+    w, h = 200, 112
+    n = capi.RT_MAX_BATCH
+    frames = []
+    for f in range(n):
+        t = [po.Transform(po.vec3(x.position.x + 0.05 * f, x.position.y, x.position.z), x.rotation) for x in tfs]
+        frames.append(t)
+    buf = torch.zeros((n, h, w, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    c.render_frames(cam, light, [conv(capi, t) for t in frames], w, h, buf)
+    c.sync()
+    got = buf.cpu().numpy()
+    for f in (0, 7, n - 1):
+        want = po.render_frame(parts, frames[f], po.default_camera(), po.default_light(), w, h)
+        assert np.array_equal(got[f], want.rgb), f
+        assert len(set(np.unique(want.hit_id[want.hit_id >= 0] >> 24).tolist())) >= 5
+    c.upload_mesh(meshes[0].tris, meshes[0].nodes, meshes[0].rgba)            # a ninth mesh
+    one = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(capi.RtError) as e:
+        c.render(cam, light, conv(capi, frames[0] + [po.Transform()]), w, h, one)
+    assert "instanced" in str(e.value)
+    c.close()
