@@ -269,7 +269,10 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * handed to the cooperative pass), "resident_budget" (variants 5..9: bytes of small meshes staged in LDS),
  * "batch_chunk" (rt_render_frames: consecutive tiles of one frame before the same tiles of the next
  * frame; 0 = four tile rows), "xcd_swizzle" (rt_render_frames: 1 = each XCD gets runs of eight neighbouring
- * tiles, default; 0 = every eighth tile), "device_build_min" (see rt_mesh_upload_soup), "sampled_split" (rt_render_frame_sampled with four samples or
+ * tiles, default; 0 = every eighth tile), "device_build_min" (see rt_mesh_upload_soup), "regroup" (1, default: a mesh uploaded through the host
+ * packer gets a second tree over the reference's own leaves, split by surface area, which rays enter instead of the
+ * reference's mean-split tree; the leaves reached, and every output, are the same; 0 = the reference's tree only;
+ * applies to meshes uploaded afterwards), "sampled_split" (rt_render_frame_sampled with four samples or
  * more: the samples of a tile are traced by four waves and added up in order instead of one wave looping
  * over them -- 0 never, 1 when the launch has fewer than 100 000 tiles (default), 2 always).
  * Every setting produces the same image.  Read-only: "n_variants", "default_variant".

@@ -83,6 +83,7 @@ struct rt_ctx {
     hipEvent_t batch_done[kBatchSlots] = {};
     bool batch_used[kBatchSlots] = {};
     unsigned batch_seq = 0;
+    int regroup = 1;               // meshes uploaded from now on get a second, surface-area-split tree over the reference's leaves
     int device_build_min = 20000;  // triangle count from which rt_mesh_upload_soup / rt_mesh_rebuild build on the device
     int sampled_split = 1;         // sampled frames: the samples of a tile spread over four waves
     float build_ms = 0.0f;         // last rt_bvh_build_device
@@ -147,9 +148,9 @@ int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tr
     dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs;
     memcpy(dm.proto.root_min, pk.root_min, 12);
     memcpy(dm.proto.root_max, pk.root_max, 12);
-    dm.proto.root_ref = pk.root_ref;
+    dm.proto.root_ref = pk.root_ref; dm.proto.ref_root = pk.ref_root;
     dm.proto.empty = pk.empty ? 1u : 0u;
-    dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.pairs.size();
+    dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.tree_pairs;
     return RT_OK;
 }
 
@@ -176,7 +177,7 @@ int build_into(rt_ctx* ctx, DeviceMesh& dm, const rt_triangle* tris, int32_t n, 
             dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs;
             memcpy(dm.proto.root_min, pk.root_min, 12);
             memcpy(dm.proto.root_max, pk.root_max, 12);
-            dm.proto.root_ref = pk.root_ref;
+            dm.proto.root_ref = pk.root_ref; dm.proto.ref_root = pk.root_ref;
             dm.proto.empty = 0u;
             dm.n_tris = n; dm.n_pairs = (int32_t)dm.pairs.size();
             return RT_OK;
@@ -190,7 +191,7 @@ int build_into(rt_ctx* ctx, DeviceMesh& dm, const rt_triangle* tris, int32_t n, 
     int st = rt_bvh_build(post.data(), n, nodes.data(), (int32_t)nodes.size(), &used);
     if (st != RT_OK) return fail(ctx, st, "BVH build failed");
     PackedMesh pk;
-    st = Packer(post.data(), n, nodes.data(), used, pk).run(why);
+    st = Packer(post.data(), n, nodes.data(), used, pk, ctx->regroup != 0).run(why);
     if (st != RT_OK) return fail(ctx, st, why);
     st = set_geometry(ctx, dm, pk, n);
     if (st == RT_OK && tris_out && n > 0) memcpy(tris_out, post.data(), (size_t)n * sizeof(rt_triangle));
@@ -207,7 +208,7 @@ int commit_scene(rt_ctx* ctx) {
     int depth = 0;
     for (auto& m : ctx->meshes) {
         m.proto.pair_base = (uint32_t)all.size();
-        m.proto.pair_count = (uint32_t)m.pairs.size();
+        m.proto.pair_count = (uint32_t)m.n_pairs;       // nodes of the tree rays enter (the heuristics' measure of a mesh)
         all.insert(all.end(), m.pairs.begin(), m.pairs.end());
         if (m.depth > depth) depth = m.depth;
     }
@@ -439,7 +440,7 @@ int rt_mesh_upload(rt_ctx* ctx, const rt_triangle* tris, int32_t n_tris, const r
     if ((int)ctx->meshes.size() >= RT_MAX_GEOMETRIES) return fail(ctx, RT_ERR_UNSUPPORTED, "too many meshes uploaded");
     PackedMesh pk;
     std::string why;
-    int st = Packer(tris, n_tris, nodes, n_nodes, pk).run(why);
+    int st = Packer(tris, n_tris, nodes, n_nodes, pk, ctx->regroup != 0).run(why);
     if (st != RT_OK) return fail(ctx, st, why);
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -466,7 +467,7 @@ int rt_mesh_replace(rt_ctx* ctx, int32_t mesh_id, const rt_triangle* tris, int32
     if (mesh_id < 0 || mesh_id >= (int32_t)ctx->meshes.size()) return fail(ctx, RT_ERR_INVALID, "no such mesh");
     PackedMesh pk;
     std::string why;
-    int st = Packer(tris, n_tris, nodes, n_nodes, pk).run(why);
+    int st = Packer(tris, n_tris, nodes, n_nodes, pk, ctx->regroup != 0).run(why);
     if (st != RT_OK) return fail(ctx, st, why);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipDeviceSynchronize());                 // frames in flight still read the old arrays
@@ -1005,6 +1006,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "sampled_split")) { ctx->sampled_split = value < 0 ? 0 : (value > 2 ? 2 : value); return RT_OK; }
     if (!strcmp(name, "device_build_min")) { ctx->device_build_min = value < 1 ? 1 : value; return RT_OK; }
+    if (!strcmp(name, "regroup")) { ctx->regroup = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "batch_chunk")) {
         if (value < 0 || value > (1 << 20)) return fail(ctx, RT_ERR_INVALID, "batch_chunk out of range");
         ctx->batch_chunk = value; return RT_OK;
@@ -1027,6 +1029,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "timing")) { *value = ctx->timing; return RT_OK; }
     if (!strcmp(name, "sampled_split")) { *value = ctx->sampled_split; return RT_OK; }
     if (!strcmp(name, "device_build_min")) { *value = ctx->device_build_min; return RT_OK; }
+    if (!strcmp(name, "regroup")) { *value = ctx->regroup; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }
     if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }

@@ -500,8 +500,9 @@ struct CoopGroup {
         const bool start = begin_query<ANY, false, false>(M, o, inv, bound, q, unused);
         int n_pair = 0, n_leaf = 0;
         if (start) {
-            if (M.root_ref & kLeafBit) { n_leaf = 1; if (j == 0) leaf_slot(0) = M.root_ref; }
-            else { n_pair = 1; if (j == 0) pair_slot(0) = M.root_ref; }
+            const uint32_t root = entry_ref<false>(M, d);
+            if (root & kLeafBit) { n_leaf = 1; if (j == 0) leaf_slot(0) = root; }
+            else { n_pair = 1; if (j == 0) pair_slot(0) = root; }
         }
         bool done = false;      // any-hit: the group has its answer
         for (;;) {

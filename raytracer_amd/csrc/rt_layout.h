@@ -79,7 +79,9 @@ struct MeshArgs {
     // Byte offsets of this mesh's PairNodes / TriRecs inside the scene's LDS-resident blob
     // (SceneArgs::resident), or kNotResident when the mesh is only in HBM.
     uint32_t res_pairs, res_tris;
-    uint32_t pad;
+    // Where the reference's own tree starts when root_ref enters a regrouped one (rt_pack.h, Packer::regroup);
+    // equal to root_ref otherwise.  Same index space as root_ref (relative to pair_base).
+    uint32_t ref_root;
 };
 constexpr uint32_t kNotResident = 0xFFFFFFFFu;
 // Small meshes (nodes + triangles) are copied into LDS by every workgroup of the lean kernels, the

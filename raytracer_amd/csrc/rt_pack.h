@@ -112,12 +112,17 @@ struct PackedMesh {
     uint32_t root_ref = kLeafBit;     // empty leaf
     bool empty = true;
     int depth = 0;                    // deepest chain of PairNodes from the root
+    // With a regrouped tree (see Packer::regroup) pairs = [regrouped tree][the reference's tree]; root_ref
+    // enters the first, ref_root the second (the visiting order and the work counts of the reference).
+    // Without one both are the same.  tree_pairs = nodes of the tree root_ref enters.
+    uint32_t ref_root = kLeafBit;
+    uint32_t tree_pairs = 0;
 };
 
 class Packer {
 public:
-    Packer(const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes, PackedMesh& out)
-        : tris_(tris), n_tris_(n_tris), nodes_(nodes), n_nodes_(n_nodes), out_(out) {}
+    Packer(const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes, PackedMesh& out, bool regroup = false)
+        : tris_(tris), n_tris_(n_tris), nodes_(nodes), n_nodes_(n_nodes), out_(out), regroup_(regroup) {}
 
     // Returns RT_OK or an rt_status; err gets the reason.
     int run(std::string& err) {
@@ -150,8 +155,11 @@ public:
         const int st = emit(0, 0, ref, err);
         if (st != RT_OK) return st;
         out_.root_ref = ref;
+        out_.ref_root = ref;
+        out_.tree_pairs = (uint32_t)out_.pairs.size();
         out_.empty = false;
         if (out_.depth + 2 > kStackDepth || out_.depth > RT_MAX_TREE_DEPTH) { err = "BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
+        if (regroup_ && leaves_ok_ && leaves_.size() >= 4 && leaves_.size() <= ((size_t)1 << 20)) regroup();
         return RT_OK;
     }
 
@@ -170,7 +178,16 @@ private:
                 covered_[(size_t)(s + i)] = 1;
                 out_.tris[(size_t)(s + i)].prio = ++next_prio_;
             }
-            return emit_leaf((uint32_t)s, (uint32_t)c, n, depth, ref, err);
+            const int st = emit_leaf((uint32_t)s, (uint32_t)c, n, depth, ref, err);
+            if (c <= kMaxLeafTris) {
+                LeafItem it;
+                memcpy(it.lo, &n.bounds_min, 12); memcpy(it.hi, &n.bounds_max, 12);
+                it.ref = ref;
+                leaves_.push_back(it);
+            } else {
+                leaves_ok_ = false;                               // a chain of PairNodes stands for this leaf
+            }
+            return st;
         }
         if (n.left < 0 || n.right < 0) { err = "internal node with a single child"; return RT_ERR_UNSUPPORTED; }
         if (out_.pairs.size() >= (size_t)kLeafBit) { err = "too many internal nodes"; return RT_ERR_UNSUPPORTED; }
@@ -213,6 +230,121 @@ private:
         return RT_OK;
     }
 
+    // ---- a second tree over the same leaves --------------------------------------------------------
+    // The reference reaches a leaf iff the slab test passes on the leaf's box and on the box of every
+    // ancestor (bvh.c:76-78, 113-124).  Every ancestor's box contains the leaf's, and the slab arithmetic
+    // (aabb.c:39-55: subtract the origin, multiply by the reciprocal direction, min/max) is monotone in the
+    // box's bounds -- a float subtraction and a float multiplication round monotonically, infinities
+    // included -- so an enclosing box's interval contains the leaf's on every axis and "tmax >= tmin &&
+    // tmax > 0" holds for it whenever it holds for the leaf.  Hence the reference tests exactly the leaves
+    // whose own box the ray passes, and ANY tree over these leaves whose inner boxes are unions of its
+    // leaves' boxes leads to the same leaves.  (Only a product 0 * inf = NaN, which fminf/fmaxf drop, can
+    // break the chain: a direction component that is exactly zero.  Rays with one take the reference's
+    // tree, see trace_mesh.)  Which leaf is visited first does not matter either: of equal t the triangle
+    // with the higher priority wins, and priorities were given in the reference's order above.
+    // The tree built here splits by a binned surface-area heuristic over the leaves' boxes; the
+    // reference's mean split costs about a sixth more box tests per ray on its own scene.
+    struct LeafItem { float lo[3], hi[3]; uint32_t ref; };
+
+    static float half_area(const float* lo, const float* hi) {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+
+    // Builds the subtree over items [first, first + count) into `fast`; returns its reference and box.
+    uint32_t regroup_range(std::vector<PairNode>& fast, size_t first, size_t count, int depth, int& deepest, float* lo, float* hi) {
+        LeafItem* it = leaves_.data() + first;
+        for (int a = 0; a < 3; a++) { lo[a] = it[0].lo[a]; hi[a] = it[0].hi[a]; }
+        if (count == 1) return it[0].ref;
+        float clo[3], chi[3];
+        for (int a = 0; a < 3; a++) { clo[a] = chi[a] = it[0].lo[a] + it[0].hi[a]; }
+        for (size_t i = 1; i < count; i++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = it[i].lo[a] < lo[a] ? it[i].lo[a] : lo[a];
+                hi[a] = it[i].hi[a] > hi[a] ? it[i].hi[a] : hi[a];
+                const float c = it[i].lo[a] + it[i].hi[a];
+                clo[a] = c < clo[a] ? c : clo[a]; chi[a] = c > chi[a] ? c : chi[a];
+            }
+        constexpr int kBins = 16;
+        float best = 3.0e38f;
+        int best_axis = -1, best_split = 0;
+        for (int a = 0; a < 3; a++) {
+            const float extent = chi[a] - clo[a];
+            if (!(extent > 0.0f)) continue;
+            float blo[kBins][3], bhi[kBins][3];
+            size_t bn[kBins] = {};
+            for (int b = 0; b < kBins; b++) for (int k = 0; k < 3; k++) { blo[b][k] = 3.0e38f; bhi[b][k] = -3.0e38f; }
+            for (size_t i = 0; i < count; i++) {
+                int b = (int)(((it[i].lo[a] + it[i].hi[a]) - clo[a]) / extent * (float)kBins);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                bn[b]++;
+                for (int k = 0; k < 3; k++) { blo[b][k] = it[i].lo[k] < blo[b][k] ? it[i].lo[k] : blo[b][k]; bhi[b][k] = it[i].hi[k] > bhi[b][k] ? it[i].hi[k] : bhi[b][k]; }
+            }
+            float rlo[kBins][3], rhi[kBins][3];
+            size_t rn[kBins];
+            float alo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ahi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            size_t an = 0;
+            for (int b = kBins - 1; b >= 0; b--) {                 // suffix boxes
+                for (int k = 0; k < 3; k++) { alo[k] = blo[b][k] < alo[k] ? blo[b][k] : alo[k]; ahi[k] = bhi[b][k] > ahi[k] ? bhi[b][k] : ahi[k]; }
+                an += bn[b];
+                for (int k = 0; k < 3; k++) { rlo[b][k] = alo[k]; rhi[b][k] = ahi[k]; }
+                rn[b] = an;
+            }
+            for (int k = 0; k < 3; k++) { alo[k] = 3.0e38f; ahi[k] = -3.0e38f; }
+            an = 0;
+            for (int split = 1; split < kBins; split++) {          // left = bins [0, split)
+                const int b = split - 1;
+                for (int k = 0; k < 3; k++) { alo[k] = blo[b][k] < alo[k] ? blo[b][k] : alo[k]; ahi[k] = bhi[b][k] > ahi[k] ? bhi[b][k] : ahi[k]; }
+                an += bn[b];
+                if (an == 0 || rn[split] == 0) continue;
+                const float cost = half_area(alo, ahi) * (float)an + half_area(rlo[split], rhi[split]) * (float)rn[split];
+                if (cost < best) { best = cost; best_axis = a; best_split = split; }
+            }
+        }
+        size_t n_left = count / 2;
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const float extent = chi[a] - clo[a];
+            size_t l = 0;
+            for (size_t i = 0; i < count; i++) {
+                int b = (int)(((it[i].lo[a] + it[i].hi[a]) - clo[a]) / extent * (float)kBins);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                if (b < best_split) { std::swap(it[i], it[l]); l++; }
+            }
+            n_left = l;
+        }
+        const uint32_t me = (uint32_t)fast.size();
+        fast.emplace_back();
+        if (depth + 1 > deepest) deepest = depth + 1;
+        PairNode p;
+        const uint32_t l = regroup_range(fast, first, n_left, depth + 1, deepest, p.lmin, p.lmax);
+        const uint32_t r = regroup_range(fast, first + n_left, count - n_left, depth + 1, deepest, p.rmin, p.rmax);
+        p.lref = l; p.rref = r; p.pad[0] = p.pad[1] = 0;
+        fast[me] = p;
+        return me;
+    }
+
+    void regroup() {
+        std::vector<PairNode> fast;
+        fast.reserve(leaves_.size());
+        int deepest = 0;
+        float lo[3], hi[3];
+        const uint32_t root = regroup_range(fast, 0, leaves_.size(), 0, deepest, lo, hi);
+        if (deepest + 2 > kStackDepth || deepest > RT_MAX_TREE_DEPTH) return;        // keep the reference's tree only
+        const uint32_t shift = (uint32_t)fast.size();
+        for (PairNode p : out_.pairs) {                           // the reference's tree moves behind the new one
+            if (!(p.lref & kLeafBit)) p.lref += shift;
+            if (!(p.rref & kLeafBit)) p.rref += shift;
+            fast.push_back(p);
+        }
+        // leaf references of the new tree that point at the reference's chain nodes do not exist (leaves_ok_)
+        out_.ref_root = (out_.root_ref & kLeafBit) ? out_.root_ref : out_.root_ref + shift;
+        out_.root_ref = root;
+        out_.tree_pairs = shift;
+        out_.pairs.swap(fast);
+        if (deepest > out_.depth) out_.depth = deepest;
+    }
+
     const rt_triangle* tris_;
     int32_t n_tris_;
     const rt_flat_node* nodes_;
@@ -220,6 +352,8 @@ private:
     PackedMesh& out_;
     std::vector<uint8_t> covered_, visited_;
     uint32_t next_prio_ = 0;
+    bool regroup_ = false, leaves_ok_ = true;
+    std::vector<LeafItem> leaves_;
 };
 
 // ------------------------------------------------------------------------------------------

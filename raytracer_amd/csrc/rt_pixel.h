@@ -172,6 +172,15 @@ RT_HD bool begin_query(const MeshArgs& M, F3 o, F3 inv, float bound, Query& q, W
 // any-hit query at the first accepted triangle; the result is the same.
 // BUDGET=true counts the nodes taken off the stack against `steps`; when it runs out the query is
 // abandoned (returns false with steps < 0) and the caller hands the pixel to the cooperative pass.
+// Where a ray enters a mesh's nodes.  The regrouped tree leads to the leaves the reference reaches as long as
+// no slab product is 0 * inf (see Packer::regroup): a ray with a direction component of exactly zero, and the
+// reference-order traversal, start in the reference's own tree.
+template <bool FULL>
+RT_HD uint32_t entry_ref(const MeshArgs& M, F3 d) {
+    if (FULL) return M.ref_root;
+    return (d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ? M.root_ref : M.ref_root;
+}
+
 template <bool ANY, bool COUNT, bool FULL, bool BUDGET, uint32_t LB, class Stack, class Nodes>
 RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& hit, Stack& stack, Work& work,
                       int& steps) {
@@ -185,7 +194,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
         // farther child is parked.  The inner loop holds nothing but box tests, the outer step
         // nothing but triangle tests, so the lanes of a wave do not drag each other through both
         // kinds of work on every step.
-        uint32_t ref = M.root_ref;
+        uint32_t ref = entry_ref<false>(M, d);
         bool live = true;
         while (live) {
             while (live && !(ref & kLeafBit)) {
@@ -219,7 +228,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
         return q.found;
     }
     // Reference order: every box whose ancestors' boxes pass, no culling.
-    stack.push(M.root_ref);
+    stack.push(entry_ref<true>(M, d));
     while (!stack.empty()) {
         if (BUDGET && --steps < 0) return false;
         const uint32_t ref = stack.pop();

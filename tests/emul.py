@@ -63,6 +63,8 @@ def lib():
                                             C.POINTER(Counters), C.POINTER(i32), C.POINTER(i32)]
         L.emul_upscale.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         L.emul_upscale.restype = None
+        L.emul_set_regroup.argtypes = [vp, i32]
+        L.emul_set_regroup.restype = None
         _lib = L
     return _lib
 
@@ -82,8 +84,9 @@ def conv(obj, cls):
 
 
 class Scene:
-    def __init__(self):
+    def __init__(self, regroup=False):
         self.h = lib().emul_scene_create()
+        lib().emul_set_regroup(self.h, 1 if regroup else 0)
         self.n = 0
         self._keep = []
 

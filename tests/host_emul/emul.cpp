@@ -38,6 +38,7 @@ struct EmulScene {
     std::vector<PairNode> all_pairs;
     std::string err;
     int stack_high = 0;
+    bool regroup = false;
 };
 }  // namespace
 
@@ -47,12 +48,13 @@ void* emul_scene_create() { return new EmulScene(); }
 void emul_scene_destroy(void* s) { delete (EmulScene*)s; }
 const char* emul_last_error(void* s) { return ((EmulScene*)s)->err.c_str(); }
 int emul_stack_high(void* s) { return ((EmulScene*)s)->stack_high; }
+void emul_set_regroup(void* s, int on) { ((EmulScene*)s)->regroup = on != 0; }   // for meshes added afterwards
 
 int emul_mesh_add(void* sp, const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes,
                   const uint8_t* rgba, int32_t tw, int32_t th) {
     EmulScene* s = (EmulScene*)sp;
     EmulMesh m;
-    int st = Packer(tris, n_tris, nodes, n_nodes, m.pk).run(s->err);
+    int st = Packer(tris, n_tris, nodes, n_nodes, m.pk, s->regroup).run(s->err);
     if (st != RT_OK) return st;
     m.texels.resize((size_t)tw * th);
     memcpy(m.texels.data(), rgba, (size_t)tw * th * 4);
@@ -104,10 +106,10 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
     for (int m = 0; m < n_tf; m++) {
         MeshArgs& M = A.mesh[m];
         const EmulMesh& E = s->meshes[(size_t)m];
-        M.pair_base = base; M.pair_count = (uint32_t)E.pk.pairs.size(); base += M.pair_count;
+        M.pair_base = base; M.pair_count = E.pk.tree_pairs; base += (uint32_t)E.pk.pairs.size();
         M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
-        M.root_ref = E.pk.root_ref; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
         fill_placement(tfs[m], A, M);
     }
     GlobalNodes nodes; nodes.all = s->all_pairs.data();
@@ -155,10 +157,10 @@ int emul_render_sampled(void* sp, const rt_camera* cam, const rt_light* lights, 
     for (int m = 0; m < n_tf; m++) {
         MeshArgs& M = A.mesh[m];
         const EmulMesh& E = s->meshes[(size_t)m];
-        M.pair_base = base; M.pair_count = (uint32_t)E.pk.pairs.size(); base += M.pair_count;
+        M.pair_base = base; M.pair_count = E.pk.tree_pairs; base += (uint32_t)E.pk.pairs.size();
         M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
-        M.root_ref = E.pk.root_ref; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
         fill_placement(tfs[m], A, M);
     }
     SampleArgs X;
@@ -203,10 +205,10 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
         const EmulMesh& E = s->meshes[(size_t)mesh_ids[i]];
         MeshArgs& M = inst[(size_t)i];
         memset(&M, 0, sizeof M);
-        M.pair_base = base[(size_t)mesh_ids[i]]; M.pair_count = (uint32_t)E.pk.pairs.size();
+        M.pair_base = base[(size_t)mesh_ids[i]]; M.pair_count = E.pk.tree_pairs;
         M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
-        M.root_ref = E.pk.root_ref; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
         fill_placement(tfs[i], A, M);
         if (!M.empty) { boxes.push_back(instance_box(tfs[i], M.root_min, M.root_max)); ids.push_back((uint32_t)i); }
     }
