@@ -3,9 +3,9 @@
 (about ten million distinct triangles), its BVH built on the GPU (rt_bvh_build_device), uploaded and
 rendered with the plain frame loop next to the ground and the drone.  Unlike the instanced form of the
 scene this working set (nodes + triangles + attributes, ~1.3 GB) does not fit any cache: the traversal
-reads HBM.  One JSON line; --check WxH also compares a small frame with the CPU oracle.
+reads HBM.  One JSON line.  (tests/test_device_build.py compares such a baked scene with the CPU oracle.)
 
-    python scripts/flat_bench.py --side 56 --frames 0,45 --check 96x54
+    python scripts/flat_bench.py --side 56 --frames 0,45
 """
 import argparse
 import json
@@ -49,7 +49,6 @@ def main():
     p.add_argument("--spacing", type=float, default=1.05)
     p.add_argument("--frames", default="0,45")
     p.add_argument("--reps", type=int, default=5)
-    p.add_argument("--check", default="", help="WxH: compare one small frame with the CPU oracle")
     p.add_argument("--host-build", action="store_true")
     p.add_argument("--profile", action="store_true", help="no work-counting launches: the program a profiler is pointed at")
     a = p.parse_args()
@@ -96,21 +95,6 @@ def main():
            "config": {"workload": f"{W}x{H}, {a.side}x{a.side} treasures baked into one mesh of {n_tris} triangles + ground + drone"},
            "dtype": "f32", "bake_s": round(t_bake, 2), "build_pack_upload_s": round(t_build, 3), "bvh_build": "host" if a.host_build else "device",
            "build_stats": stats, "frames": rows}
-    if a.check:
-        cw, ch = [int(x) for x in a.check.split("x")]
-        from oracle import pyoracle as po
-        small = torch.empty((ch, cw, 3), dtype=torch.uint8, device=dev)
-        hid = torch.empty((ch, cw), dtype=torch.int32, device=dev)
-        tfs = [scene.transforms(45)[0], capi.Transform(), capi.Transform()]
-        ctx.render(scene.camera, scene.light, tfs, cw, ch, small, hit_id=hid)
-        ctx.sync()
-        own = po.default_meshes()                                 # the oracle's own load of the same assets
-        tris, nodes = po.build_bvh(soup)                          # the oracle's own build of the same soup
-        meshes = [own[0], po.HostMesh(tris, nodes, rgba[1]), own[2]]
-        ptfs = [po.animation_transforms(45)[0], po.Transform(), po.Transform()]
-        want = po.render_frame(meshes, ptfs, po.default_camera(), po.default_light(), cw, ch)
-        out["oracle_check"] = {"size": a.check, "hit_ids_equal": bool(np.array_equal(hid.cpu().numpy(), want.hit_id)),
-                               "rgb_equal": bool(np.array_equal(small.cpu().numpy(), want.rgb))}
     print(json.dumps(out), flush=True)
     ctx.close()
     scene.close()

@@ -240,3 +240,40 @@ def test_upload_soup_edge_cases_and_rebuild(capi, po):
         assert np.array_equal(hid.cpu().numpy(), want.hit_id) and np.array_equal(rgb.cpu().numpy(), want.rgb)
         assert len(set(np.unique(want.hit_id[want.hit_id >= 0] >> 24).tolist())) >= 2
     c.close()
+
+
+def test_baked_grid_of_meshes_as_one_mesh_against_the_oracle(capi, po):
+    """Copies of the treasure baked into one soup of half a million triangles, built and packed on the device,
+    rendered by the plain frame loop: the frame of the reference loop on the oracle's own build of that soup."""
+    import torch
+    meshes = po.default_meshes()
+    treasure = po.load_obj(os.path.join(po.ASSETS, "treasure.obj"))
+    rng = np.random.default_rng(3)
+    side, parts = 13, []
+    for gx in range(side):
+        for gz in range(side):
+            parts.append(bake(treasure, float(rng.uniform(0, 6.28)), ((gx - 6) * 1.05, 0.45 + 0.1 * float(rng.uniform()), (gz - 6) * 1.05)))
+    soup = np.concatenate(parts)
+    assert soup.shape[0] > 500_000
+    c = capi.Context(0)
+    c.upload_mesh(meshes[0].tris, meshes[0].nodes, meshes[0].rgba)
+    mid, post = c.upload_soup(soup, meshes[1].rgba, want_triangles=True)
+    assert c.build_stats()["levels"] > 15                                      # went through the device build
+    c.upload_mesh(meshes[2].tris, meshes[2].nodes, meshes[2].rgba)
+    want_t, want_n = po.build_bvh(soup)
+    assert np.array_equal(post.view(np.uint32), want_t.view(np.uint32))
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    pl = po.default_light()
+    light = capi.Light(capi.Vec3(*pl.direction.tup()), capi.Vec3(*pl.color.tup()))
+    w, h = 192, 108
+    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    hid = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+    t0 = po.animation_transforms(45)[0]
+    c.render(cam, light, [capi.Transform(capi.Vec3(*t0.position.tup()), capi.Vec3(*t0.rotation.tup())), capi.Transform(), capi.Transform()],
+             w, h, rgb, hit_id=hid)
+    c.sync()
+    want = po.render_frame([meshes[0], po.HostMesh(want_t, want_n, meshes[1].rgba), meshes[2]], [t0, po.Transform(), po.Transform()],
+                           po.default_camera(), po.default_light(), w, h)
+    assert np.array_equal(hid.cpu().numpy(), want.hit_id) and np.array_equal(rgb.cpu().numpy(), want.rgb)
+    assert ((want.hit_id >> 24) == 1).mean() > 0.3
+    c.close()
