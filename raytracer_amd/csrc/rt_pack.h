@@ -502,11 +502,19 @@ struct Tlas {
 
 class TlasBuilder {
 public:
-    // boxes[k] belongs to instance ids[k]; median split of the centroids along their longest axis,
-    // leaves of at most two instances.
+    // boxes[k] belongs to instance ids[k]; binned surface-area split of the centroids (median split along the
+    // longest axis where that finds nothing, or for the whole tree if it comes out too deep), leaves of at most
+    // two instances.
     TlasBuilder(const std::vector<InstanceBox>& boxes, const std::vector<uint32_t>& ids, Tlas& out) : boxes_(boxes), ids_(ids), out_(out) {}
 
     void run() {
+        build(true);
+        if (out_.depth + 2 > kTlasStackDepth) build(false);      // a lopsided surface-area tree: the median split is balanced
+    }
+
+private:
+    void build(bool by_area) {
+        by_area_ = by_area;
         out_ = Tlas();
         std::vector<uint32_t> items(boxes_.size());
         for (size_t i = 0; i < items.size(); i++) items[i] = (uint32_t)i;
@@ -517,7 +525,6 @@ public:
         memcpy(out_.root_min, root.lo, 12); memcpy(out_.root_max, root.hi, 12);
     }
 
-private:
     uint32_t emit(uint32_t* items, size_t n, int depth, InstanceBox& box) {
         for (int i = 0; i < 3; i++) { box.lo[i] = INFINITY; box.hi[i] = -INFINITY; }
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -535,14 +542,73 @@ private:
             for (size_t k = 0; k < n; k++) out_.order.push_back(ids_[items[k]]);
             return leaf_ref(first, (uint32_t)n);
         }
-        int axis = 0;
-        if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
-        if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
-        const size_t mid = n / 2;
-        std::nth_element(items, items + mid, items + n, [&](uint32_t a, uint32_t b) {
-            const float ca = boxes_[a].lo[axis] + boxes_[a].hi[axis], cb = boxes_[b].lo[axis] + boxes_[b].hi[axis];
-            return ca < cb || (ca == cb && a < b);
-        });
+        // Binned surface-area split over the centroids (a huge instance, e.g. a ground plane, ends up alone near
+        // the root instead of inflating every box above it); median split along the longest axis when no bin
+        // boundary separates the items.
+        size_t mid = n / 2;
+        {
+            constexpr int kBins = 16;
+            float best = INFINITY;
+            int best_axis = -1, best_split = 0;
+            for (int a = 0; a < 3 && by_area_; a++) {
+                const float extent = chi[a] - clo[a];
+                if (!(extent > 0.0f)) continue;
+                InstanceBox bb[kBins];
+                size_t bn[kBins] = {};
+                for (int b = 0; b < kBins; b++) for (int i = 0; i < 3; i++) { bb[b].lo[i] = INFINITY; bb[b].hi[i] = -INFINITY; }
+                auto bin_of = [&](uint32_t it) {
+                    const float c = 0.5f * boxes_[it].lo[a] + 0.5f * boxes_[it].hi[a];
+                    int b = (int)((c - clo[a]) / extent * (float)kBins);
+                    return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                };
+                for (size_t k = 0; k < n; k++) {
+                    const int b = bin_of(items[k]);
+                    bn[b]++;
+                    for (int i = 0; i < 3; i++) {
+                        bb[b].lo[i] = boxes_[items[k]].lo[i] < bb[b].lo[i] ? boxes_[items[k]].lo[i] : bb[b].lo[i];
+                        bb[b].hi[i] = boxes_[items[k]].hi[i] > bb[b].hi[i] ? boxes_[items[k]].hi[i] : bb[b].hi[i];
+                    }
+                }
+                auto area = [](const InstanceBox& x) { const float dx = x.hi[0] - x.lo[0], dy = x.hi[1] - x.lo[1], dz = x.hi[2] - x.lo[2]; return dx * dy + dy * dz + dz * dx; };
+                InstanceBox suffix[kBins];
+                size_t sn[kBins];
+                InstanceBox acc; size_t an = 0;
+                for (int i = 0; i < 3; i++) { acc.lo[i] = INFINITY; acc.hi[i] = -INFINITY; }
+                for (int b = kBins - 1; b >= 0; b--) {
+                    for (int i = 0; i < 3; i++) { acc.lo[i] = bb[b].lo[i] < acc.lo[i] ? bb[b].lo[i] : acc.lo[i]; acc.hi[i] = bb[b].hi[i] > acc.hi[i] ? bb[b].hi[i] : acc.hi[i]; }
+                    an += bn[b]; suffix[b] = acc; sn[b] = an;
+                }
+                for (int i = 0; i < 3; i++) { acc.lo[i] = INFINITY; acc.hi[i] = -INFINITY; }
+                an = 0;
+                for (int split = 1; split < kBins; split++) {
+                    const int b = split - 1;
+                    for (int i = 0; i < 3; i++) { acc.lo[i] = bb[b].lo[i] < acc.lo[i] ? bb[b].lo[i] : acc.lo[i]; acc.hi[i] = bb[b].hi[i] > acc.hi[i] ? bb[b].hi[i] : acc.hi[i]; }
+                    an += bn[b];
+                    if (an == 0 || sn[split] == 0) continue;
+                    const float cost = area(acc) * (float)an + area(suffix[split]) * (float)sn[split];
+                    if (cost < best) { best = cost; best_axis = a; best_split = split; }
+                }
+            }
+            if (best_axis >= 0) {
+                const int a = best_axis;
+                const float extent = chi[a] - clo[a];
+                uint32_t* m = std::partition(items, items + n, [&](uint32_t it) {
+                    const float c = 0.5f * boxes_[it].lo[a] + 0.5f * boxes_[it].hi[a];
+                    int b = (int)((c - clo[a]) / extent * (float)kBins);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    return b < best_split;
+                });
+                mid = (size_t)(m - items);
+            } else {
+                int axis = 0;
+                if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+                if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+                std::nth_element(items, items + mid, items + n, [&](uint32_t a, uint32_t b) {
+                    const float ca = boxes_[a].lo[axis] + boxes_[a].hi[axis], cb = boxes_[b].lo[axis] + boxes_[b].hi[axis];
+                    return ca < cb || (ca == cb && a < b);
+                });
+            }
+        }
         const uint32_t me = (uint32_t)out_.pairs.size();
         out_.pairs.emplace_back();
         if (depth + 1 > out_.depth) out_.depth = depth + 1;
@@ -559,6 +625,7 @@ private:
     const std::vector<InstanceBox>& boxes_;
     const std::vector<uint32_t>& ids_;
     Tlas& out_;
+    bool by_area_ = true;
 };
 
 }  // namespace rt
