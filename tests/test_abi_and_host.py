@@ -89,6 +89,14 @@ def test_no_gpu_means_an_error_not_a_cpu_render(capi, host):
     assert L.rt_mesh_count(None) == capi.RT_ERR_INVALID
     assert L.rt_render_frame(None, None, None, None, 0, 8, 8, 0, None, None, None, None, None) == capi.RT_ERR_INVALID
     assert L.rt_render_frames(None, None, None, None, 1, 0, 8, 8, None, 192, None) == capi.RT_ERR_INVALID
+    assert L.rt_render_frame_strips(None, None, None, None, 0, 8, 8, 2, 0, 0, None, None, None, None, None) == capi.RT_ERR_INVALID
+    assert L.rt_mesh_upload_soup(None, None, 0, None, 1, 1, None, None) == capi.RT_ERR_INVALID
+    assert L.rt_mesh_rebuild(None, 0, None, 0, None) == capi.RT_ERR_INVALID
+    assert L.rt_bvh_build_device(None, None, 0, None, 0, None) == capi.RT_ERR_INVALID
+    # page-locked memory needs the device runtime: the caller falls back to malloc (create_scene below does)
+    p = C.c_void_p()
+    assert L.rt_pinned_alloc(4096, C.byref(p)) == capi.RT_ERR_NO_DEVICE and not p.value
+    assert L.rt_pinned_free(None) == 0
     # the reference API: render_scene reports the failure and leaves the frame untouched
     H = host.lib()
     scene = H.create_scene(64, 48, 1000, 4, 1.0)
