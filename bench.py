@@ -114,17 +114,7 @@ def main():
             print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     from raytracer_amd import demo, sharding
-    # create_mesh prints what it loaded on stdout, like the reference (mesh.c:112); stdout is kept for the
-    # one JSON line, so those lines go to stderr
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        scene = demo.DemoScene(local)
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved, 1)
-        os.close(saved)
+    scene = demo.DemoScene(local)           # its loader's printf lines go to stderr: stdout is kept for the one JSON line
     say("scene loaded")
     ctx = scene.ctx
     if a.block:

@@ -3,8 +3,10 @@ ground meshes loaded with the host API's create_mesh, camera and light as the dr
 and the per-frame placements of its animation loop."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
+import sys
 from typing import List
 
 from . import capi, host_api
@@ -13,18 +15,34 @@ MESH_NAMES = ("drone", "treasure", "ground")          # raytracer.c:27-34, in ad
 N_FRAMES = (4000 * 24) // 1000                        # raytracer.c:10 -> scene.c:9
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """create_mesh reports what it loaded with printf, like the reference (mesh.c:112).  Programs that keep
+    stdout for one JSON line send those lines to stderr while the scene loads."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class DemoScene:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, quiet_stdout: bool = True):
         H = host_api.lib()
         self.ctx = capi.Context(device)
         self.meshes = []
-        for name in MESH_NAMES:
-            m = H.create_mesh(os.path.join(host_api.ASSETS, name + ".obj").encode(),
-                              os.path.join(host_api.ASSETS, name + ".webp").encode())
-            if not m.bvh.root or not m.texture_data:
-                raise RuntimeError(f"could not load {name}")
-            self.meshes.append(m)
-            self.ctx.upload_host_mesh(m)
+        with (stdout_to_stderr() if quiet_stdout else contextlib.nullcontext()):
+            for name in MESH_NAMES:
+                m = H.create_mesh(os.path.join(host_api.ASSETS, name + ".obj").encode(),
+                                  os.path.join(host_api.ASSETS, name + ".webp").encode())
+                if not m.bvh.root or not m.texture_data:
+                    raise RuntimeError(f"could not load {name}")
+                self.meshes.append(m)
+                self.ctx.upload_host_mesh(m)
         cam = H.create_camera(host_api.Vec3(-3, 3, -3), host_api.Vec3(0, 0, 0), host_api.Vec3(0, 1, 0), 60.0)   # raytracer.c:13-18
         lit = H.create_directional_light(host_api.Vec3(1, 1, -1), host_api.Vec3(1.4, 1.4, 1.4))                 # raytracer.c:21-24
         self.camera = capi.Camera(capi.Vec3(cam.position.x, cam.position.y, cam.position.z),
