@@ -35,6 +35,23 @@ struct DeviceMesh {
 
 }  // namespace
 
+namespace {
+// What rt_render_frame_instanced computed for list entry i last time (see there).
+struct InstanceCache {
+    bool valid = false;
+    rt_transform transform;
+    float root_min[3], root_max[3];
+    MeshArgs placed;
+    InstanceBox box;
+};
+
+void copy_placement(const MeshArgs& from, MeshArgs& to) {
+    memcpy(to.inv, from.inv, sizeof(to.inv)); memcpy(to.wrow, from.wrow, sizeof(to.wrow)); memcpy(to.nrm, from.nrm, sizeof(to.nrm));
+    memcpy(to.cam_o, from.cam_o, sizeof(to.cam_o)); memcpy(to.lit_d, from.lit_d, sizeof(to.lit_d)); memcpy(to.lit_inv, from.lit_inv, sizeof(to.lit_inv));
+    to.w_mode = from.w_mode;
+}
+}  // namespace
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -86,6 +103,8 @@ struct rt_ctx {
     int regroup = 1;               // meshes uploaded from now on get a second, surface-area-split tree over the reference's leaves
     int device_build_min = 20000;  // triangle count from which rt_mesh_upload_soup / rt_mesh_rebuild build on the device
     int sampled_split = 1;         // sampled frames: the samples of a tile spread over four waves
+    std::vector<InstanceCache> inst_cache;
+    float inst_cache_cam[3] = {0, 0, 0}, inst_cache_light[3] = {0, 0, 0};
     float build_ms = 0.0f;         // last rt_bvh_build_device
     int build_levels = 0, build_launches = 0;
     std::string err;
@@ -814,10 +833,28 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
     std::vector<InstanceBox> boxes;
     std::vector<uint32_t> ids;
     boxes.reserve((size_t)n_instances); ids.reserve((size_t)n_instances);
+    // Placement constants and world boxes are kept from the previous call: an entry whose transform (and the
+    // camera position and light direction its constants depend on) did not change is copied, not recomputed --
+    // in a scene of thousands of placed meshes most stand still from frame to frame.
+    if (memcmp(ctx->inst_cache_cam, A.cam_pos, 12) != 0 || memcmp(ctx->inst_cache_light, A.light_dir, 12) != 0) {
+        ctx->inst_cache.clear();
+        memcpy(ctx->inst_cache_cam, A.cam_pos, 12); memcpy(ctx->inst_cache_light, A.light_dir, 12);
+    }
+    ctx->inst_cache.resize((size_t)n_instances);
     for (int32_t i = 0; i < n_instances; i++) {
         inst[i] = ctx->meshes[(size_t)instances[i].mesh].proto;
-        fill_placement(instances[i].transform, A, inst[i]);
-        if (!inst[i].empty) { boxes.push_back(instance_box(instances[i].transform, inst[i].root_min, inst[i].root_max)); ids.push_back((uint32_t)i); }
+        InstanceCache& c = ctx->inst_cache[(size_t)i];
+        const bool same = c.valid && memcmp(&c.transform, &instances[i].transform, sizeof(rt_transform)) == 0 &&
+                          memcmp(c.root_min, inst[i].root_min, 12) == 0 && memcmp(c.root_max, inst[i].root_max, 12) == 0;
+        if (same) {
+            copy_placement(c.placed, inst[i]);
+        } else {
+            fill_placement(instances[i].transform, A, inst[i]);
+            c.valid = true; c.transform = instances[i].transform; c.placed = inst[i];
+            memcpy(c.root_min, inst[i].root_min, 12); memcpy(c.root_max, inst[i].root_max, 12);
+            c.box = instance_box(instances[i].transform, inst[i].root_min, inst[i].root_max);
+        }
+        if (!inst[i].empty) { boxes.push_back(c.box); ids.push_back((uint32_t)i); }
     }
     Tlas T;
     TlasBuilder(boxes, ids, T).run();

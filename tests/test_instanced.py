@@ -273,3 +273,40 @@ def test_gpu_reference_api_scene_with_repeated_meshes(po, meshes):
     for m in loaded:
         L.destroy_mesh(C.byref(m))
     L.destroy_scene(C.byref(scene))
+
+
+@pytest.mark.gpu
+def test_gpu_successive_calls_with_partly_changed_lists(gscene, po, meshes):
+    """Placement constants are kept between calls for entries whose transform did not change: a sequence of
+    calls on one context (some entries moved, a mesh swapped, the list shortened and lengthened, a different
+    light) gives what the reference loop gives for each list."""
+    import torch
+    from raytracer_amd import capi
+    ids, tfs = grid_scene(po, 6, seed=11)
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    w, h = 160, 90
+    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    hi = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+    rng = np.random.default_rng(5)
+    lights = [po.default_light(), po.lib().orc_make_light(po.vec3(-0.3, 1, 0.4), po.vec3(1.0, 0.9, 0.8))]
+    steps = []
+    cur_ids, cur_tfs = list(ids), list(tfs)
+    steps.append((list(cur_ids), list(cur_tfs), 0))
+    for k in (3, 7, 20):                                                         # a few entries move
+        cur_tfs[k] = po.Transform(po.vec3(*rng.uniform(-2, 2, 3) * [1, 0.2, 1] + [0, 0.8, 0]), po.vec3(0, float(rng.uniform(0, 6)), 0))
+    steps.append((list(cur_ids), list(cur_tfs), 0))
+    cur_ids[5] = 0 if cur_ids[5] != 0 else 1                                     # same transform, another mesh
+    steps.append((list(cur_ids), list(cur_tfs), 0))
+    steps.append((cur_ids[:10], cur_tfs[:10], 0))                                # shorter, then the long list again
+    steps.append((list(cur_ids), list(cur_tfs), 0))
+    steps.append((list(cur_ids), list(cur_tfs), 1))                              # another light: every constant changes
+    steps.append((list(ids), list(tfs), 0))
+    for s_ids, s_tfs, li in steps:
+        l = lights[li]
+        light = capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
+        inst = capi.Context.make_instances(s_ids, [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in s_tfs])
+        gscene.render_instanced(cam, light, inst, w, h, rgb, hit_instance=hi)
+        gscene.sync()
+        fr, inst_want, _ = oracle_planes(po, meshes, s_ids, s_tfs, po.default_camera(), l, w, h)
+        assert np.array_equal(hi.cpu().numpy(), inst_want)
+        assert np.array_equal(rgb.cpu().numpy(), fr.rgb)
