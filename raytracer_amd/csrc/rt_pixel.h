@@ -165,13 +165,6 @@ RT_HD bool begin_query(const MeshArgs& M, F3 o, F3 inv, float bound, Query& q, W
     return !(CULL && entry > q.limit);
 }
 
-// Closest hit (ANY=false) or any hit (ANY=true) of one mesh by ONE lane, ray already in mesh space.
-// FULL=true reproduces the reference's work exactly: every box whose ancestors' slabs all pass is
-// visited, and an any-hit query keeps going after its first accepted triangle.
-// FULL=false visits the nearer child first, skips boxes beyond the closest hit so far, and ends an
-// any-hit query at the first accepted triangle; the result is the same.
-// BUDGET=true counts the nodes taken off the stack against `steps`; when it runs out the query is
-// abandoned (returns false with steps < 0) and the caller hands the pixel to the cooperative pass.
 // Where a ray enters a mesh's nodes.  The regrouped tree leads to the leaves the reference reaches as long as
 // no slab product is 0 * inf (see Packer::regroup): a ray with a direction component of exactly zero, and the
 // reference-order traversal, start in the reference's own tree.
@@ -181,6 +174,13 @@ RT_HD uint32_t entry_ref(const MeshArgs& M, F3 d) {
     return (d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ? M.root_ref : M.ref_root;
 }
 
+// Closest hit (ANY=false) or any hit (ANY=true) of one mesh by ONE lane, ray already in mesh space.
+// FULL=true reproduces the reference's work exactly: every box whose ancestors' slabs all pass is
+// visited, and an any-hit query keeps going after its first accepted triangle.
+// FULL=false visits the nearer child first, skips boxes beyond the closest hit so far, and ends an
+// any-hit query at the first accepted triangle; the result is the same.
+// BUDGET=true counts the nodes taken off the stack against `steps`; when it runs out the query is
+// abandoned (returns false with steps < 0) and the caller hands the pixel to the cooperative pass.
 template <bool ANY, bool COUNT, bool FULL, bool BUDGET, uint32_t LB, class Stack, class Nodes>
 RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& hit, Stack& stack, Work& work,
                       int& steps) {
