@@ -59,7 +59,7 @@ RT_HD bool beats(bool a_found, const Hit& a, bool b_found, const Hit& b) {
     return a_found && (!b_found || a.t < b.t || (a.t == b.t && a.prio > b.prio));
 }
 
-constexpr uint32_t kLeafBatch = 4;       // triangles fetched together in a leaf
+constexpr uint32_t kLeafBatch = 2;       // triangles fetched together in a leaf
 
 // Slab tests of both children of a PairNode (aabb.c:33-56 twice), entry distances reported.
 #if defined(__HIP_DEVICE_COMPILE__)
