@@ -263,6 +263,8 @@ def main():
                 roof["traffic_note"] = "HBM bytes per %s launch of 8 frames from FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, profiles/traffic.json" % pmc.get("kernel")
                 roof["valu"]["issue_utilisation_pmc"] = pmc.get("valu_issue_utilisation")
                 roof["valu"]["lane_utilisation_pmc"] = pmc.get("valu_lane_utilisation")
+                roof["binding"] = "FP32 VALU issue: %.0f %% of issue cycles busy, %.0f %% of lanes active (counters of an earlier run)" % (
+                    100.0 * pmc.get("valu_issue_utilisation", 0.0), 100.0 * pmc.get("valu_lane_utilisation", 0.0))
             except Exception:
                 pass
 
