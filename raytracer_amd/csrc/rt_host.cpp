@@ -878,7 +878,7 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    hipError_t le = launch_instanced(A, I, S, O, (int32_t*)d_hit_tri, ctx->cfg.block, s);
+    hipError_t le = launch_instanced(A, I, S, O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, s);
     if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
     RT_HIP(ctx, hipEventRecord(ctx->inst_done[slot], s));

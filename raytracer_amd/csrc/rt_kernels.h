@@ -48,7 +48,7 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
 // S.pairs, live tris/attrs/texels), I.tlas / I.order the hierarchy over the non-empty ones, its depth at
 // most kTlasStackDepth - 2.  O.hit_id receives the instance index, hit_tri (optional) the triangle.
 hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const SceneArgs& S, const OutputPlanes& O, int32_t* hit_tri,
-                            int block, hipStream_t stream);
+                            int tlas_entries, int block, hipStream_t stream);
 
 // Enqueues the bicubic upscale of n_frames RGB8 frames (width x height, frame f at rgb + f*frame_stride
 // bytes) to ARGB32 frames (scaled_width x scaled_height, frame f at argb + f*out_stride pixels).

@@ -273,12 +273,13 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
 // ------------------------------------------------------------------------------------------
 template <int BLOCK, bool COUNT>
 __global__ void __launch_bounds__(BLOCK) render_instanced(const FrameArgs A, const InstancedArgs I, const SceneArgs S, const OutputPlanes O,
-                                                          int32_t* __restrict__ hit_tri) {
-    __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
-    __shared__ uint32_t lds_tstack[kTlasStackDepth * BLOCK];
+                                                          int32_t* __restrict__ hit_tri, const int tlas_entries) {
+    // both stacks sized for the trees at hand (entries x BLOCK words each): LDS per wave decides how many
+    // waves a CU holds here
+    extern __shared__ uint32_t lds_stacks[];
     LdsStack<BLOCK> stack, tstack;
-    stack.init(&lds_stack[threadIdx.x]);
-    tstack.init(&lds_tstack[threadIdx.x]);
+    tstack.init(&lds_stacks[threadIdx.x]);
+    stack.init(&lds_stacks[(size_t)tlas_entries * BLOCK + threadIdx.x]);
     GlobalNodes nodes; nodes.all = S.pairs;
     const int tiles_x = (A.width + 7) >> 3;
     const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -301,18 +302,21 @@ __global__ void __launch_bounds__(BLOCK) render_instanced(const FrameArgs A, con
 }
 
 hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const SceneArgs& S, const OutputPlanes& O, int32_t* hit_tri,
-                            int block, hipStream_t stream) {
+                            int tlas_entries, int block, hipStream_t stream) {
     if (A.width <= 0 || A.height <= 0 || !O.rgb || I.n_inst < 0 || (I.n_inst > 0 && (!I.inst || !I.order))) return hipErrorInvalidValue;
+    if (tlas_entries < 2 || tlas_entries > kTlasStackDepth || S.stack_entries < 2 || S.stack_entries > (uint32_t)kStackDepth) return hipErrorInvalidValue;
     const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
     if (count && !O.counters) return hipErrorInvalidValue;
     const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
+    const int threads = block == 256 ? 256 : 64;
+    const size_t lds = (size_t)(tlas_entries + (int)S.stack_entries) * (size_t)threads * sizeof(uint32_t);
     if (block == 256) {
         const int blocks = (tiles + 3) / 4;
-        if (count) hipLaunchKernelGGL((render_instanced<256, true>), dim3(blocks), dim3(256), 0, stream, A, I, S, O, hit_tri);
-        else       hipLaunchKernelGGL((render_instanced<256, false>), dim3(blocks), dim3(256), 0, stream, A, I, S, O, hit_tri);
+        if (count) hipLaunchKernelGGL((render_instanced<256, true>), dim3(blocks), dim3(256), lds, stream, A, I, S, O, hit_tri, tlas_entries);
+        else       hipLaunchKernelGGL((render_instanced<256, false>), dim3(blocks), dim3(256), lds, stream, A, I, S, O, hit_tri, tlas_entries);
     } else {
-        if (count) hipLaunchKernelGGL((render_instanced<64, true>), dim3(tiles), dim3(64), 0, stream, A, I, S, O, hit_tri);
-        else       hipLaunchKernelGGL((render_instanced<64, false>), dim3(tiles), dim3(64), 0, stream, A, I, S, O, hit_tri);
+        if (count) hipLaunchKernelGGL((render_instanced<64, true>), dim3(tiles), dim3(64), lds, stream, A, I, S, O, hit_tri, tlas_entries);
+        else       hipLaunchKernelGGL((render_instanced<64, false>), dim3(tiles), dim3(64), lds, stream, A, I, S, O, hit_tri, tlas_entries);
     }
     return hipGetLastError();
 }
