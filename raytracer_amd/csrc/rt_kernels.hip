@@ -137,7 +137,7 @@ static hipError_t launch_direct(const FrameArgs& A, const SceneArgs& S, const Ou
 // ------------------------------------------------------------------------------------------
 template <int BLOCK, bool COUNT>
 __global__ void __launch_bounds__(BLOCK) render_sampled(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
-    __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
+    extern __shared__ uint32_t lds_stack[];                      // S.stack_entries x BLOCK words
     LdsStack<BLOCK> stack;
     stack.init(&lds_stack[threadIdx.x]);
     GlobalNodes nodes; nodes.all = S.pairs;
@@ -247,6 +247,8 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
     const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
     if (count && !O.counters) return hipErrorInvalidValue;
     const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
+    if (S.stack_entries < 2 || S.stack_entries > (uint32_t)kStackDepth) return hipErrorInvalidValue;
+    const size_t stack_bytes = (size_t)S.stack_entries * 64 * sizeof(uint32_t);     // per wave
     const size_t dyn = (size_t)X.spp * 192 * sizeof(float);
     const size_t fixed = (size_t)kStackDepth * 64 * kSplitWaves * sizeof(uint32_t) + 4096;
     // split = 1: when the launch has too few tiles to hide a tile's sample loop behind other tiles (measured at
@@ -257,11 +259,11 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
         else       hipLaunchKernelGGL((render_sampled_split<false>), dim3(tiles), dim3(64 * kSplitWaves), dyn, stream, A, X, S, O);
     } else if (block == 256) {
         const int blocks = (tiles + 3) / 4;
-        if (count) hipLaunchKernelGGL((render_sampled<256, true>), dim3(blocks), dim3(256), 0, stream, A, X, S, O);
-        else       hipLaunchKernelGGL((render_sampled<256, false>), dim3(blocks), dim3(256), 0, stream, A, X, S, O);
+        if (count) hipLaunchKernelGGL((render_sampled<256, true>), dim3(blocks), dim3(256), stack_bytes * 4, stream, A, X, S, O);
+        else       hipLaunchKernelGGL((render_sampled<256, false>), dim3(blocks), dim3(256), stack_bytes * 4, stream, A, X, S, O);
     } else {
-        if (count) hipLaunchKernelGGL((render_sampled<64, true>), dim3(tiles), dim3(64), 0, stream, A, X, S, O);
-        else       hipLaunchKernelGGL((render_sampled<64, false>), dim3(tiles), dim3(64), 0, stream, A, X, S, O);
+        if (count) hipLaunchKernelGGL((render_sampled<64, true>), dim3(tiles), dim3(64), stack_bytes, stream, A, X, S, O);
+        else       hipLaunchKernelGGL((render_sampled<64, false>), dim3(tiles), dim3(64), stack_bytes, stream, A, X, S, O);
     }
     return hipGetLastError();
 }
