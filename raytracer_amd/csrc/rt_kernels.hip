@@ -180,8 +180,8 @@ constexpr int kSplitWaves = 4;
 template <bool COUNT>
 __global__ void __launch_bounds__(64 * kSplitWaves) render_sampled_split(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
     constexpr int BLOCK = 64 * kSplitWaves;
-    __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
-    extern __shared__ float lds_values[];                       // [spp][3][64]
+    extern __shared__ float lds_values[];                       // [spp][3][64], then S.stack_entries x BLOCK stack words
+    uint32_t* lds_stack = reinterpret_cast<uint32_t*>(lds_values + (size_t)X.spp * 192);
     __shared__ uint32_t lds_counts[kSplitWaves][2][64];
     __shared__ int32_t lds_hit_id[64];
     LdsStack<BLOCK> stack;
@@ -249,10 +249,10 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
     const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
     if (S.stack_entries < 2 || S.stack_entries > (uint32_t)kStackDepth) return hipErrorInvalidValue;
     const size_t stack_bytes = (size_t)S.stack_entries * 64 * sizeof(uint32_t);     // per wave
-    const size_t dyn = (size_t)X.spp * 192 * sizeof(float);
-    const size_t fixed = (size_t)kStackDepth * 64 * kSplitWaves * sizeof(uint32_t) + 4096;
+    const size_t dyn = (size_t)X.spp * 192 * sizeof(float) + stack_bytes * kSplitWaves;
+    const size_t fixed = 4096;
     // split = 1: when the launch has too few tiles to hide a tile's sample loop behind other tiles (measured at
-    // 16 samples: 65 k tiles 6.1 ms split / 7.2 ms looped, 130 k tiles 12.0 / 9.9); 2: always.
+    // 16 samples: 65 k tiles 4.7 ms split / 6.9 ms looped, 130 k tiles 9.4 / 8.3); 2: always.
     const bool want = split == 2 || (split == 1 && tiles <= 100000);
     if (want && X.spp >= kSplitWaves && dyn + fixed <= 64 * 1024) {      // 64 KB of LDS per workgroup without opting in to more
         if (count) hipLaunchKernelGGL((render_sampled_split<true>), dim3(tiles), dim3(64 * kSplitWaves), dyn, stream, A, X, S, O);

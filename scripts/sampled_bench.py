@@ -25,12 +25,15 @@ def main():
     p.add_argument("--frames", default="0,45")
     p.add_argument("--reps", type=int, default=3)
     p.add_argument("--shares", default="2,4,8", help="also render the frame as N interleaved strip shares (what N GPUs would each do)")
+    p.add_argument("--split", type=int, default=-1, help="context option sampled_split: 0 looped, 1 by tile count (default), 2 always four waves per tile")
     a = p.parse_args()
     from raytracer_amd import capi, demo, host_api as H
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     scene = demo.DemoScene(0)
     ctx = scene.ctx
+    if a.split >= 0:
+        ctx.set_option("sampled_split", a.split)
     L = H.lib()
     dirs = [(1, 1, -1), (-1, 2, 0.5), (0.2, 1, 0.8), (-0.5, 0.7, -1)]
     cols = [(1.4, 1.4, 1.4), (0.3, 0.5, 0.9), (0.5, 0.2, 0.2), (0.2, 0.4, 0.2)]
