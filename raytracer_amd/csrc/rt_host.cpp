@@ -52,6 +52,8 @@ void copy_placement(const MeshArgs& from, MeshArgs& to) {
 }
 }  // namespace
 
+constexpr int kRingSlots = 8;      // most frames rt_render_frame_host keeps in flight
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -103,6 +105,15 @@ struct rt_ctx {
     int regroup = 1;               // meshes uploaded from now on get a second, surface-area-split tree over the reference's leaves
     int device_build_min = 20000;  // triangle count from which rt_mesh_upload_soup / rt_mesh_rebuild build on the device
     int sampled_split = 1;         // sampled frames: the samples of a tile spread over four waves
+    // rt_render_frame_host with option "frames_in_flight" > 1: each call takes the next slot of a ring (its own
+    // stream and device image), queues kernel + copy to the caller's buffer and returns; rt_sync waits for all.
+    int frames_in_flight = 1;
+    hipStream_t ring_stream[kRingSlots] = {};
+    hipEvent_t ring_done[kRingSlots] = {};
+    uint8_t* ring_rgb[kRingSlots] = {};
+    size_t ring_pixels[kRingSlots] = {};
+    bool ring_used[kRingSlots] = {};
+    unsigned ring_seq = 0;
     std::vector<InstanceCache> inst_cache;
     float inst_cache_cam[3] = {0, 0, 0}, inst_cache_light[3] = {0, 0, 0};
     float build_ms = 0.0f;         // last rt_bvh_build_device
@@ -398,6 +409,11 @@ int rt_ctx_destroy(rt_ctx* ctx) {
         if (ctx->h_inst[i]) (void)hipHostFree(ctx->h_inst[i]);
         if (ctx->d_inst[i]) (void)hipFree(ctx->d_inst[i]);
     }
+    for (int i = 0; i < kRingSlots; i++) {
+        if (ctx->ring_stream[i]) { (void)hipStreamSynchronize(ctx->ring_stream[i]); (void)hipStreamDestroy(ctx->ring_stream[i]); }
+        if (ctx->ring_done[i]) (void)hipEventDestroy(ctx->ring_done[i]);
+        if (ctx->ring_rgb[i]) (void)hipFree(ctx->ring_rgb[i]);
+    }
     if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
@@ -665,6 +681,36 @@ int render_frame_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* ligh
     return RT_OK;
 }
 
+// One frame through the next slot of the ring: kernel and copy are queued on the slot's stream and the call
+// returns.  Frames in flight overlap on the GPU, so the plain tile kernel is used: the tiles that run long in
+// one frame are covered by the next frame's tiles, as in a batch.  The variants that keep work lists in the
+// context would have to run one after another.
+int render_frame_in_flight(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms, int32_t n_transforms,
+                           int32_t width, int32_t height, uint32_t flags, uint8_t* h_rgb) {
+    const size_t pixels = (size_t)width * (size_t)height;
+    const int slots = ctx->frames_in_flight < kRingSlots ? ctx->frames_in_flight : kRingSlots;
+    const int slot = (int)(ctx->ring_seq++ % (unsigned)slots);
+    if (!ctx->ring_stream[slot]) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->ring_stream[slot], hipStreamNonBlocking));
+    if (!ctx->ring_done[slot]) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ring_done[slot], hipEventDisableTiming));
+    if (ctx->ring_used[slot]) { RT_HIP(ctx, hipEventSynchronize(ctx->ring_done[slot])); ctx->ring_used[slot] = false; }
+    if (pixels > ctx->ring_pixels[slot]) {
+        if (ctx->ring_rgb[slot]) (void)hipFree(ctx->ring_rgb[slot]);
+        ctx->ring_rgb[slot] = nullptr; ctx->ring_pixels[slot] = 0;
+        RT_HIP(ctx, hipMalloc((void**)&ctx->ring_rgb[slot], pixels * 3));
+        ctx->ring_pixels[slot] = pixels;
+    }
+    const int variant = ctx->cfg.variant, timing = ctx->timing;
+    ctx->cfg.variant = 0; ctx->timing = 0;             // no per-frame event pair either: its times would overlap
+    const int st = render_frame_impl(ctx, camera, light, transforms, n_transforms, width, height, 1, 0, flags, ctx->ring_rgb[slot], nullptr, nullptr,
+                                     nullptr, ctx->ring_stream[slot]);
+    ctx->cfg.variant = variant; ctx->timing = timing;
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, hipMemcpyAsync(h_rgb, ctx->ring_rgb[slot], pixels * 3, hipMemcpyDeviceToHost, ctx->ring_stream[slot]));
+    RT_HIP(ctx, hipEventRecord(ctx->ring_done[slot], ctx->ring_stream[slot]));
+    ctx->ring_used[slot] = true;
+    return RT_OK;
+}
+
 int bad_strips(rt_ctx* ctx, int32_t stride, int32_t offset) {
     if (!ctx) return RT_ERR_INVALID;
     if (stride < 1 || offset < 0 || offset >= stride) return fail(ctx, RT_ERR_INVALID, "strips: need stride >= 1 and 0 <= offset < stride");
@@ -894,6 +940,8 @@ int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* l
     if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t pixels = (size_t)width * (size_t)height;
+    if (ctx->frames_in_flight > 1 && !h_hit_id && !h_hit_t && !h_shadow && (flags & RT_FLAG_COUNT_WORK) == 0)
+        return render_frame_in_flight(ctx, camera, light, transforms, n_transforms, width, height, flags, h_rgb);
     int st = ensure_planes(ctx, pixels);
     if (st != RT_OK) return st;
     st = rt_render_frame(ctx, camera, light, transforms, n_transforms, width, height, flags, ctx->d_rgb,
@@ -997,6 +1045,9 @@ int rt_sync(rt_ctx* ctx, void* stream) {
     if (!ctx) return RT_ERR_INVALID;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    if (!stream)                                      // and the frames rt_render_frame_host left in flight
+        for (int i = 0; i < kRingSlots; i++)
+            if (ctx->ring_used[i]) { RT_HIP(ctx, hipEventSynchronize(ctx->ring_done[i])); ctx->ring_used[i] = false; }
     return RT_OK;
 }
 
@@ -1044,6 +1095,12 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "sampled_split")) { ctx->sampled_split = value < 0 ? 0 : (value > 2 ? 2 : value); return RT_OK; }
     if (!strcmp(name, "device_build_min")) { ctx->device_build_min = value < 1 ? 1 : value; return RT_OK; }
     if (!strcmp(name, "regroup")) { ctx->regroup = value ? 1 : 0; return RT_OK; }
+    if (!strcmp(name, "frames_in_flight")) {
+        if (value < 1 || value > kRingSlots) return fail(ctx, RT_ERR_INVALID, "frames_in_flight must be 1..8");
+        const int st = rt_sync(ctx, nullptr);            // the ring is empty whenever its length changes
+        if (st != RT_OK) return st;
+        ctx->frames_in_flight = value; ctx->ring_seq = 0; return RT_OK;
+    }
     if (!strcmp(name, "batch_chunk")) {
         if (value < 0 || value > (1 << 20)) return fail(ctx, RT_ERR_INVALID, "batch_chunk out of range");
         ctx->batch_chunk = value; return RT_OK;
@@ -1067,6 +1124,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "sampled_split")) { *value = ctx->sampled_split; return RT_OK; }
     if (!strcmp(name, "device_build_min")) { *value = ctx->device_build_min; return RT_OK; }
     if (!strcmp(name, "regroup")) { *value = ctx->regroup; return RT_OK; }
+    if (!strcmp(name, "frames_in_flight")) { *value = ctx->frames_in_flight; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }
     if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }

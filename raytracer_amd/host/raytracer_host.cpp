@@ -36,6 +36,7 @@ struct MeshKey {
 };
 struct SceneState {
     rt_ctx* ctx = nullptr;
+    int in_flight = 1;                    // the context's "frames_in_flight" as last set
     std::vector<MeshKey> geometries;      // distinct (triangles, BVH, texture) uploaded, in upload order
     int last_status = 0;
 };
@@ -43,6 +44,7 @@ std::mutex g_lock;
 std::map<const void*, SceneState> g_states;
 std::map<const void*, void*> g_pinned_frames;    // Scene.frames array -> the page-locked block its frames live in
 int g_device = -1;
+int g_in_flight = 1;                              // rt_host_set_frames_in_flight
 
 int pick_device() {
     if (g_device >= 0) return g_device;
@@ -88,11 +90,24 @@ int sync_scene(Scene* scene, SceneState& st, std::vector<int32_t>& geometry_of) 
     return RT_OK;
 }
 
+// Waits for the frames render_scene left in flight (g_lock held by the caller).
+int wait_frames(SceneState* st) {
+    if (!st || !st->ctx || st->in_flight <= 1) return RT_OK;
+    const int rc = rt_sync(st->ctx, nullptr);
+    if (rc != RT_OK) { fprintf(stderr, "render_scene: %s (%s)\n", rt_status_string(rc), rt_last_error(st->ctx)); st->last_status = rc; }
+    return rc;
+}
+
 int render_into(Scene* scene, uint8_t* rgb, int32_t* hit_id, float* hit_t, uint8_t* shadow) {
     std::lock_guard<std::mutex> g(g_lock);
     SceneState* st = state_of(scene, true);
     std::vector<int32_t> geometry_of;
     int rc = sync_scene(scene, *st, geometry_of);
+    const int in_flight = (hit_id || hit_t || shadow) ? 1 : g_in_flight;
+    if (rc == RT_OK && st->in_flight != in_flight) {
+        rc = rt_set_option(st->ctx, "frames_in_flight", in_flight);      // waits for the frames queued so far
+        if (rc == RT_OK) st->in_flight = in_flight;
+    }
     if (rc == RT_OK) {
         // one mesh per geometry, in order, and few enough: the plain frame; otherwise the mesh list is a
         // list of placed geometries
@@ -393,6 +408,7 @@ void save_scene(Scene* scene, const char* filename) {                           
     // frame times as the reference gives them to its encoder (scene.c:204, 209).  No status is
     // returned, like the reference; problems are reported on stderr.
     if (!scene || !filename || !scene->frames || scene->frame_count <= 0) return;
+    if (rt_host_wait(scene) != RT_OK) return;
     int sw = 0, sh = 0;
     if (rt_host_scaled_size(scene, &sw, &sh) != RT_OK) { fprintf(stderr, "save_scene: bad scene size\n"); return; }
     rt_host_animation* anim = nullptr;
@@ -419,6 +435,7 @@ void destroy_scene(Scene* scene) {                                              
         std::lock_guard<std::mutex> g(g_lock);
         auto it = g_states.find((const void*)scene->frames);
         if (it != g_states.end()) {
+            (void)wait_frames(&it->second);                    // copies into scene->frames may still be queued
             if (it->second.ctx) rt_ctx_destroy(it->second.ctx);
             g_states.erase(it);
         }
@@ -481,10 +498,20 @@ int rt_host_upscale_frame(Scene* scene, int index, uint32_t* argb) {            
         rc = rt_ctx_create(pick_device(), &st->ctx);
         if (rc != RT_OK) { fprintf(stderr, "rt_host_upscale_frame: cannot open GPU %d: %s\n", pick_device(), rt_status_string(rc)); st->last_status = rc; return rc; }
     }
+    rc = wait_frames(st);
+    if (rc != RT_OK) return rc;
     rc = rt_upscale_frame_host(st->ctx, scene->frames[index], scene->width, scene->height, sw, sh, argb);
     if (rc != RT_OK) fprintf(stderr, "rt_host_upscale_frame: %s (%s)\n", rt_status_string(rc), rt_last_error(st->ctx));
     st->last_status = rc;
     return rc;
+}
+
+void rt_host_set_frames_in_flight(int n) { std::lock_guard<std::mutex> g(g_lock); g_in_flight = n < 1 ? 1 : (n > 8 ? 8 : n); }
+
+int rt_host_wait(Scene* scene) {
+    if (!scene) return RT_ERR_INVALID;
+    std::lock_guard<std::mutex> g(g_lock);
+    return wait_frames(state_of(scene, false));
 }
 
 void rt_host_set_obj_mode(int tolerant) { g_obj_mode = tolerant ? 1 : 0; }
@@ -493,6 +520,8 @@ void rt_host_set_save_options(float quality, int threads) { g_save_quality = qua
 
 int rt_host_write_ppm(const Scene* scene, int index, const char* filename) {
     if (!scene || !filename || index < 0 || index >= scene->frame_count) return RT_ERR_INVALID;
+    const int rc = rt_host_wait(const_cast<Scene*>(scene));
+    if (rc != RT_OK) return rc;
     FILE* f = fopen(filename, "wb");
     if (!f) return RT_ERR_INVALID;
     fprintf(f, "P6\n%d %d\n255\n", scene->width, scene->height);

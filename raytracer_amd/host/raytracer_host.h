@@ -154,6 +154,15 @@ int rt_host_animation_has_webp(void);
 int rt_host_animation_open(const char* filename, int width, int height, float quality, int threads, rt_host_animation** out);
 int rt_host_animation_add(rt_host_animation* a, const void* pixels, int format, int duration_ms);
 int rt_host_animation_close(rt_host_animation* a);
+/* Frames render_scene may leave in flight (1..8; default 1 = every call returns with its frame in
+ * scene->frames[current_frame], like the reference).  With n > 1 render_scene queues the frame's kernel and
+ * its copy into scene->frames[current_frame] and returns; the frame is complete after rt_host_wait(scene),
+ * and save_scene, rt_host_upscale_frame, rt_host_write_ppm, rt_host_render_debug and destroy_scene wait by
+ * themselves.  A driver that only renders and then saves (raytracer.c:36-63) needs no other change.
+ * Applies to scenes of this process from their next render_scene on. */
+void rt_host_set_frames_in_flight(int n);
+/* Waits until every frame render_scene has queued for this scene is in scene->frames.  Returns 0 or a negative rt_status. */
+int rt_host_wait(Scene* scene);
 /* Encoder settings save_scene uses: quality as above (default 75), threads as above (default 0). */
 void rt_host_set_save_options(float quality, int threads);
 

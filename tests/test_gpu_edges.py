@@ -166,3 +166,37 @@ def test_limits_eight_meshes_and_sixteen_frames(capi, po, meshes):
         c.render(cam, light, conv(capi, frames[0] + [po.Transform()]), w, h, one)
     assert "instanced" in str(e.value)
     c.close()
+
+
+def test_frames_in_flight_through_the_c_abi(capi, po, meshes):
+    """rt_render_frame_host with option frames_in_flight: calls return before their frame has arrived, rt_sync(ctx, NULL)
+    waits for all of them; pageable destinations, more frames than slots, a change of size in between, a call that
+    asks for debug planes (always waits), and values outside 1..8 refused."""
+    c = capi.Context(0)
+    for m in meshes:
+        c.upload_mesh(m.tris, m.nodes, m.rgba)
+    cam, light = camera_light(capi, po)
+    rng = np.random.default_rng(11)
+    placements = [[po.Transform(po.vec3(*(rng.uniform(-1.5, 1.5, 3) * [1, 0.2, 1] + [0, 1, 0])), po.vec3(0, float(rng.uniform(0, 6)), 0)),
+                   po.Transform(po.vec3(float(rng.uniform(-1, 1)), 0.5, 0), po.vec3(0, float(rng.uniform(0, 6)), 0)), po.Transform()]
+                  for _ in range(7)]
+    sizes = [(161, 90)] * 4 + [(96, 131)] * 3
+    want = [c.render_host(cam, light, conv(capi, t), w, h, debug=False)[0] for t, (w, h) in zip(placements, sizes)]
+    oracle = po.render_frame(list(meshes), placements[2], po.default_camera(), po.default_light(), *sizes[2])
+    assert np.array_equal(want[2], oracle.rgb)
+    assert c.get_option("frames_in_flight") == 1
+    for bad in (0, 9, -1):
+        with pytest.raises(capi.RtError):
+            c.set_option("frames_in_flight", bad)
+    for depth in (2, 3):
+        c.set_option("frames_in_flight", depth)
+        assert c.get_option("frames_in_flight") == depth
+        got = [c.render_host(cam, light, conv(capi, t), w, h, debug=False)[0] for t, (w, h) in zip(placements, sizes)]
+        rgb, hid, _, _ = c.render_host(cam, light, conv(capi, placements[2]), *sizes[2], debug=True)      # waits for its own frame
+        assert np.array_equal(rgb, oracle.rgb) and np.array_equal(hid, oracle.hit_id)
+        c.sync()
+        for k in range(len(got)):
+            assert np.array_equal(got[k], want[k]), (depth, k)
+    c.set_option("frames_in_flight", 1)
+    assert np.array_equal(c.render_host(cam, light, conv(capi, placements[0]), *sizes[0], debug=False)[0], want[0])
+    c.close()

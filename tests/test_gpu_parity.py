@@ -309,6 +309,75 @@ def test_save_scene_writes_the_upscaled_animation(po, tmp_path):
     L.destroy_scene(C.byref(scene))
 
 
+def test_render_scene_with_frames_in_flight(po, tmp_path):
+    """render_scene that returns before its frame has arrived (rt_host_set_frames_in_flight): after rt_host_wait the
+    frames are the ones the waiting calls deliver, with more frames than ring slots, a mesh edit between frames
+    (which drains the ring), a debug render in between, and save_scene waiting by itself."""
+    import ctypes as C
+    import os
+    Image = pytest.importorskip("PIL.Image")
+    from raytracer_amd import host_api as H
+    L = H.lib()
+    scene = L.create_scene(200, 120, 1100, 10, 1.0)                    # 11 frames
+    assert scene.frame_count == 11
+    L.set_scene_camera(C.byref(scene), H.Vec3(-3, 3, -3), H.Vec3(0, 0, 0), H.Vec3(0, 1, 0), 60.0)
+    L.set_scene_light(C.byref(scene), H.Vec3(1, 1, -1), H.Vec3(1.4, 1.4, 1.4))
+    loaded = []
+    for n in NAMES:
+        m = L.create_mesh(os.path.join(H.ASSETS, n + ".obj").encode(), os.path.join(H.ASSETS, n + ".webp").encode())
+        loaded.append(m)
+        L.add_mesh_to_scene(C.byref(scene), m)
+
+    def animate(debug_at=-1):
+        scene.current_frame = 0
+        for frame in range(scene.frame_count):
+            drone, treasure = H.Transform(), H.Transform()
+            L.rt_host_demo_animation(frame * 9, C.byref(drone), C.byref(treasure))
+            L.set_mesh_position(C.byref(scene.meshes[0]), drone.position)
+            L.set_mesh_rotation(C.byref(scene.meshes[0]), drone.rotation)
+            L.set_mesh_position(C.byref(scene.meshes[1]), treasure.position)
+            L.render_scene(C.byref(scene))
+            assert L.rt_host_last_status(C.byref(scene)) == 0
+            if frame == debug_at:
+                ids = np.empty((scene.height, scene.width), np.int32)
+                assert L.rt_host_render_debug(C.byref(scene), ids.ctypes.data, None, None) == 0
+                assert (ids >= 0).any()
+            L.next_frame(C.byref(scene))
+
+    animate()
+    want = [H.frame_array(scene, f).copy() for f in range(scene.frame_count)]
+    assert not np.array_equal(want[0], want[5])
+    for depth in (2, 3, 8):
+        for f in range(scene.frame_count):
+            C.memset(scene.frames[f], 0, scene.width * scene.height * 3)
+        L.rt_host_set_frames_in_flight(depth)
+        animate(debug_at=4 if depth == 3 else -1)
+        assert L.rt_host_wait(C.byref(scene)) == 0
+        for f in range(scene.frame_count):
+            assert np.array_equal(H.frame_array(scene, f), want[f]), (depth, f)
+    # save_scene and rt_host_write_ppm wait by themselves
+    for f in range(scene.frame_count):
+        C.memset(scene.frames[f], 0, scene.width * scene.height * 3)
+    animate()
+    ppm = str(tmp_path / "last.ppm")
+    assert L.rt_host_write_ppm(C.byref(scene), scene.frame_count - 1, ppm.encode()) == 0
+    with open(ppm, "rb") as fh:
+        assert fh.read()[-want[-1].size:] == want[-1].tobytes()
+    animate()
+    path = str(tmp_path / "in_flight.webp")
+    L.rt_host_set_save_options(-1.0, 2)
+    L.save_scene(C.byref(scene), path.encode())
+    L.rt_host_set_save_options(75.0, 0)
+    im = Image.open(path)
+    assert im.n_frames == scene.frame_count
+    im.seek(scene.frame_count - 1)
+    assert np.array_equal(np.asarray(im.convert("RGB")), want[-1])      # scale factor 1: the rendered pixels
+    L.rt_host_set_frames_in_flight(1)
+    for m in loaded:
+        L.destroy_mesh(C.byref(m))
+    L.destroy_scene(C.byref(scene))
+
+
 def test_animation_sink_consumes_gathered_batches(po, tmp_path):
     """Frames go from the gather's consume hook through the GPU upscale into the animation file while later
     batches render; the per-rank batches of one gather interleave to consecutive frames."""
