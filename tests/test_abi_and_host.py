@@ -77,6 +77,20 @@ def test_status_strings(capi):
     assert capi.status_string(-99) == "unknown status"
 
 
+def test_c_driver_on_the_host_api_stops_without_a_gpu(host, tmp_path):
+    """examples/drone_animation.c is plain C11 on raytracer_host.h (built by `make examples`): without a GPU it loads the
+    meshes, render_scene reports why it cannot render, and the program stops without writing a file."""
+    exe = os.path.join(REPO, "examples", "drone_animation")
+    assert os.path.exists(exe), "run `make examples`"
+    if gpu_present():
+        pytest.skip("a GPU is present")
+    out = str(tmp_path / "never.webp")
+    r = subprocess.run([exe, host.ASSETS, out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert "no usable GPU" in r.stderr and "frame 0 failed" in r.stderr
+    assert not os.path.exists(out) and not os.path.exists(out + ".ppm")
+
+
 def test_no_gpu_means_an_error_not_a_cpu_render(capi, host):
     if gpu_present():
         pytest.skip("a GPU is present")

@@ -378,6 +378,34 @@ def test_render_scene_with_frames_in_flight(po, tmp_path):
     L.destroy_scene(C.byref(scene))
 
 
+def test_c_driver_renders_the_reference_animation(po, golden_hashes, tmp_path):
+    """examples/drone_animation.c: a C11 program that makes the reference driver's calls (raytracer.c:8-75) and is
+    linked against the host library.  Its frames 0, 45 and 95 are the golden frames of the compiled reference, with
+    every call waiting and with four frames in flight, and the file it saves holds 96 frames of 800x600."""
+    import json
+    import os
+    import subprocess
+    Image = pytest.importorskip("PIL.Image")
+    from raytracer_amd import host_api as H
+    from conftest import REPO
+    exe = os.path.join(REPO, "examples", "drone_animation")
+    assert os.path.exists(exe), "run `make examples`"
+    for in_flight in (1, 4):
+        out = str(tmp_path / f"anim{in_flight}.webp")
+        prefix = str(tmp_path / f"frame{in_flight}")
+        r = subprocess.run([exe, H.ASSETS, out, str(in_flight), prefix], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        assert (info["frames"], info["width"], info["height"], info["frames_in_flight"]) == (96, 720, 540, in_flight)
+        for frame in (0, 45, 95):
+            raw = open(f"{prefix}_{frame}.ppm", "rb").read()
+            head = b"P6\n720 540\n255\n"
+            assert raw.startswith(head) and len(raw) == len(head) + 720 * 540 * 3
+            assert hashlib.sha256(raw[len(head):]).hexdigest() == golden_hashes["frames"][f"720x540_f{frame}"]["rgb"], (in_flight, frame)
+        im = Image.open(out)
+        assert im.size == (800, 600) and im.n_frames == 96
+
+
 def test_animation_sink_consumes_gathered_batches(po, tmp_path):
     """Frames go from the gather's consume hook through the GPU upscale into the animation file while later
     batches render; the per-rank batches of one gather interleave to consecutive frames."""
