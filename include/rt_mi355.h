@@ -280,7 +280,9 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * applies to meshes uploaded afterwards), "sampled_split" (rt_render_frame_sampled with four samples or
  * more: the samples of a tile are traced by four waves and added up in order instead of one wave looping
  * over them -- 0 never, 1 when the launch has fewer than 100 000 tiles (default), 2 always),
- * "frames_in_flight" (1..8, default 1: see rt_render_frame_host).
+ * "frames_in_flight" (1..8, default 1: see rt_render_frame_host), "keep_hierarchy" (rt_render_frame_instanced:
+ * 1, default = the hierarchy over the instances is kept between calls and patched while few instances change
+ * their place; 0 = built anew for every call).
  * Every setting produces the same image.  Read-only: "n_variants", "default_variant".
  * Unknown names give RT_ERR_INVALID. */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);

@@ -115,6 +115,8 @@ struct rt_ctx {
     bool ring_used[kRingSlots] = {};
     unsigned ring_seq = 0;
     std::vector<InstanceCache> inst_cache;
+    StandingTlas standing;         // rt_render_frame_instanced: the hierarchy over the instances, kept between calls
+    int keep_hierarchy = 1;
     float inst_cache_cam[3] = {0, 0, 0}, inst_cache_light[3] = {0, 0, 0};
     float build_ms = 0.0f;         // last rt_bvh_build_device
     int build_levels = 0, build_launches = 0;
@@ -861,7 +863,9 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
     const int slot = (int)(ctx->inst_seq++ % (unsigned)kInstSlots);
     if (ctx->inst_used[slot]) RT_HIP(ctx, hipEventSynchronize(ctx->inst_done[slot]));
     const size_t n = (size_t)(n_instances > 0 ? n_instances : 1);
-    const size_t off_pairs = (n * sizeof(MeshArgs) + 63) & ~(size_t)63, off_order = off_pairs + n * sizeof(PairNode), total = off_order + ((n * sizeof(uint32_t) + 63) & ~(size_t)63);
+    // a kept hierarchy that was patched holds its old leaves too: room for twice the instances
+    const size_t off_pairs = (n * sizeof(MeshArgs) + 63) & ~(size_t)63, off_order = off_pairs + (2 * n + 2) * sizeof(PairNode),
+                 total = off_order + (((2 * n + 2) * sizeof(uint32_t) + 63) & ~(size_t)63);
     if (n > ctx->inst_capacity[slot]) {
         if (ctx->h_inst[slot]) (void)hipHostFree(ctx->h_inst[slot]);
         if (ctx->d_inst[slot]) (void)hipFree(ctx->d_inst[slot]);
@@ -903,8 +907,10 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
         if (!inst[i].empty) { boxes.push_back(c.box); ids.push_back((uint32_t)i); }
     }
     Tlas T;
-    TlasBuilder(boxes, ids, T).run();
+    if (ctx->keep_hierarchy) (void)ctx->standing.update(boxes, ids, (size_t)n_instances, T);
+    else TlasBuilder(boxes, ids, T).run();
     if (T.depth + 2 > kTlasStackDepth) return fail(ctx, RT_ERR_UNSUPPORTED, "instance hierarchy deeper than its stack");
+    if (T.pairs.size() > 2 * n + 2 || T.order.size() > 2 * n + 2) return fail(ctx, RT_ERR_DEVICE, "instance hierarchy larger than its staging area");
     if (!T.pairs.empty()) memcpy(h + off_pairs, T.pairs.data(), T.pairs.size() * sizeof(PairNode));
     if (!T.order.empty()) memcpy(h + off_order, T.order.data(), T.order.size() * sizeof(uint32_t));
     RT_HIP(ctx, hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
@@ -1095,6 +1101,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "sampled_split")) { ctx->sampled_split = value < 0 ? 0 : (value > 2 ? 2 : value); return RT_OK; }
     if (!strcmp(name, "device_build_min")) { ctx->device_build_min = value < 1 ? 1 : value; return RT_OK; }
     if (!strcmp(name, "regroup")) { ctx->regroup = value ? 1 : 0; return RT_OK; }
+    if (!strcmp(name, "keep_hierarchy")) { ctx->keep_hierarchy = value ? 1 : 0; ctx->standing.clear(); return RT_OK; }
     if (!strcmp(name, "frames_in_flight")) {
         if (value < 1 || value > kRingSlots) return fail(ctx, RT_ERR_INVALID, "frames_in_flight must be 1..8");
         const int st = rt_sync(ctx, nullptr);            // the ring is empty whenever its length changes
@@ -1125,6 +1132,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "device_build_min")) { *value = ctx->device_build_min; return RT_OK; }
     if (!strcmp(name, "regroup")) { *value = ctx->regroup; return RT_OK; }
     if (!strcmp(name, "frames_in_flight")) { *value = ctx->frames_in_flight; return RT_OK; }
+    if (!strcmp(name, "keep_hierarchy")) { *value = ctx->keep_hierarchy; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }
     if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }

@@ -136,7 +136,7 @@ constexpr int kTlasStackDepth = 32;
 struct InstancedArgs {
     const MeshArgs* inst;        // n_inst records
     int32_t n_inst;
-    uint32_t tlas_root;          // leaf ref or PairNode index 0 of `tlas`
+    uint32_t tlas_root;          // leaf ref or index of the root PairNode in `tlas`
     const PairNode* tlas;
     const uint32_t* order;       // instance indices, grouped by hierarchy leaf
     float root_min[3], root_max[3];

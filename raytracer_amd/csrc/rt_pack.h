@@ -500,6 +500,8 @@ struct Tlas {
     int depth = 0;
 };
 
+constexpr size_t kTlasLeaf = 1;      // instances per leaf of the hierarchy
+
 class TlasBuilder {
 public:
     // boxes[k] belongs to instance ids[k]; binned surface-area split of the centroids (median split along the
@@ -537,7 +539,7 @@ private:
                 clo[i] = c < clo[i] ? c : clo[i]; chi[i] = c > chi[i] ? c : chi[i];
             }
         }
-        if (n <= 2) {
+        if (n <= kTlasLeaf) {
             const uint32_t first = (uint32_t)out_.order.size();
             for (size_t k = 0; k < n; k++) out_.order.push_back(ids_[items[k]]);
             return leaf_ref(first, (uint32_t)n);
@@ -626,6 +628,100 @@ private:
     const std::vector<uint32_t>& ids_;
     Tlas& out_;
     bool by_area_ = true;
+};
+
+// The hierarchy of a scene that is rendered frame after frame with most instances standing still.
+//
+// A hierarchy built once is kept.  For the next frame the instances whose box changed (moved, swapped
+// for another mesh, emptied or filled) are counted; if they are few, the kept tree is copied, their
+// leaves in it are emptied (the boxes above stay as they are: larger than needed, never too small),
+// a small tree is built over them where they are now, and a new root joins the two.  Any hierarchy
+// whose boxes contain the instances below them proposes every instance a ray can reach, so the
+// rendered frame is the same; only the walk's cost depends on the tree.  The kept tree is the one
+// from the last full build, so patches do not pile up; when many instances changed, or the list's
+// length did, the tree is built anew and kept.
+class StandingTlas {
+public:
+    // boxes[k] belongs to instance ids[k] (the non-empty instances, ids ascending) of a list of n_instances.
+    // Fills `out` with this frame's hierarchy.  Returns true when the kept tree was reused.
+    bool update(const std::vector<InstanceBox>& boxes, const std::vector<uint32_t>& ids, size_t n_instances, Tlas& out) {
+        static_assert(kTlasLeaf == 1, "emptying a leaf removes exactly one instance");
+        has_now_.assign(n_instances, 0);
+        where_now_.assign(n_instances, 0);
+        for (size_t k = 0; k < ids.size(); k++) { has_now_[ids[k]] = 1; where_now_[ids[k]] = (uint32_t)k; }
+        if (valid_ && kept_has_.size() == n_instances && !kept_.pairs.empty()) {
+            const size_t limit = n_instances / 16 > 8 ? n_instances / 16 : 8;
+            std::vector<uint32_t> changed;
+            for (size_t i = 0; i < n_instances && changed.size() <= limit; i++) {
+                const bool same = has_now_[i] == kept_has_[i] && (!has_now_[i] || memcmp(&boxes[where_now_[i]], &kept_box_[i], sizeof(InstanceBox)) == 0);
+                if (!same) changed.push_back((uint32_t)i);
+            }
+            if (changed.size() <= limit && patch(boxes, ids, changed, out)) return true;
+        }
+        TlasBuilder(boxes, ids, kept_).run();
+        kept_has_ = has_now_;
+        kept_box_.assign(n_instances, InstanceBox());
+        for (size_t k = 0; k < ids.size(); k++) kept_box_[ids[k]] = boxes[k];
+        slot_.assign(n_instances, kNoSlot);
+        for (size_t p = 0; p < kept_.pairs.size(); p++)
+            for (uint32_t side = 0; side < 2; side++) {
+                const uint32_t ref = side ? kept_.pairs[p].rref : kept_.pairs[p].lref;
+                if (!(ref & kLeafBit)) continue;
+                const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
+                for (uint32_t k = 0; k < count; k++) slot_[kept_.order[first + k]] = (uint32_t)p * 2u + side;
+            }
+        valid_ = true;
+        out = kept_;
+        return false;
+    }
+
+    void clear() { valid_ = false; }
+
+private:
+    static constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+
+    bool patch(const std::vector<InstanceBox>& boxes, const std::vector<uint32_t>& ids, const std::vector<uint32_t>& changed, Tlas& out) {
+        out = kept_;
+        if (changed.empty()) return true;
+        std::vector<InstanceBox> moved_boxes;
+        std::vector<uint32_t> moved_ids;
+        for (uint32_t i : changed) {
+            if (kept_has_[i]) {
+                if (slot_[i] == kNoSlot) return false;
+                PairNode& p = out.pairs[slot_[i] >> 1];
+                ((slot_[i] & 1u) ? p.rref : p.lref) = leaf_ref(0, 0);          // a leaf without instances
+            }
+            if (has_now_[i]) { moved_boxes.push_back(boxes[where_now_[i]]); moved_ids.push_back(ids[where_now_[i]]); }
+        }
+        if (moved_ids.empty()) return true;
+        Tlas small;
+        TlasBuilder(moved_boxes, moved_ids, small).run();
+        const uint32_t pair_shift = (uint32_t)out.pairs.size(), order_shift = (uint32_t)out.order.size();
+        if ((size_t)order_shift + small.order.size() > 0x00FFFFFFu) return false;
+        auto shifted = [&](uint32_t ref) { return (ref & kLeafBit) ? ref + order_shift : ref + pair_shift; };
+        for (PairNode p : small.pairs) { p.lref = shifted(p.lref); p.rref = shifted(p.rref); out.pairs.push_back(p); }
+        out.order.insert(out.order.end(), small.order.begin(), small.order.end());
+        PairNode join;
+        memcpy(join.lmin, kept_.root_min, 12); memcpy(join.lmax, kept_.root_max, 12);
+        memcpy(join.rmin, small.root_min, 12); memcpy(join.rmax, small.root_max, 12);
+        join.lref = kept_.root_ref; join.rref = shifted(small.root_ref); join.pad[0] = join.pad[1] = 0;
+        out.root_ref = (uint32_t)out.pairs.size();
+        out.pairs.push_back(join);
+        for (int i = 0; i < 3; i++) {
+            out.root_min[i] = small.root_min[i] < kept_.root_min[i] ? small.root_min[i] : kept_.root_min[i];
+            out.root_max[i] = small.root_max[i] > kept_.root_max[i] ? small.root_max[i] : kept_.root_max[i];
+        }
+        out.depth = (small.depth > kept_.depth ? small.depth : kept_.depth) + 1;
+        return out.depth + 2 <= kTlasStackDepth;
+    }
+
+    Tlas kept_;
+    std::vector<InstanceBox> kept_box_;     // per instance of the list the kept tree was built for
+    std::vector<uint8_t> kept_has_;         // ... whether it is in the tree (not an empty mesh)
+    std::vector<uint32_t> slot_;            // ... and where its leaf hangs: PairNode index * 2 + side
+    std::vector<uint8_t> has_now_;
+    std::vector<uint32_t> where_now_;
+    bool valid_ = false;
 };
 
 }  // namespace rt

@@ -65,6 +65,9 @@ def lib():
         L.emul_upscale.restype = None
         L.emul_set_regroup.argtypes = [vp, i32]
         L.emul_set_regroup.restype = None
+        L.emul_keep_hierarchy.argtypes = [vp, i32]
+        L.emul_keep_hierarchy.restype = None
+        L.emul_hierarchy_reused.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -160,6 +163,13 @@ class Scene:
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_inst": inst, "hit_tri": tri, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(),
                 "tlas_pairs": pairs.value, "tlas_depth": depth.value}
+
+    def keep_hierarchy(self, on: bool):
+        """Instanced frames from now on keep the hierarchy over the instances between calls, as the product does."""
+        lib().emul_keep_hierarchy(self.h, 1 if on else 0)
+
+    def hierarchy_reused(self) -> int:
+        return lib().emul_hierarchy_reused(self.h)
 
     def close(self):
         if self.h:

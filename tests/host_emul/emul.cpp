@@ -39,6 +39,9 @@ struct EmulScene {
     std::string err;
     int stack_high = 0;
     bool regroup = false;
+    bool keep_hierarchy = false;       // instanced frames: the product's hierarchy kept from call to call
+    StandingTlas standing;
+    int hierarchy_reused = 0;          // calls that reused the kept tree
 };
 }  // namespace
 
@@ -48,6 +51,8 @@ void* emul_scene_create() { return new EmulScene(); }
 void emul_scene_destroy(void* s) { delete (EmulScene*)s; }
 const char* emul_last_error(void* s) { return ((EmulScene*)s)->err.c_str(); }
 int emul_stack_high(void* s) { return ((EmulScene*)s)->stack_high; }
+void emul_keep_hierarchy(void* s, int on) { ((EmulScene*)s)->keep_hierarchy = on != 0; ((EmulScene*)s)->standing.clear(); ((EmulScene*)s)->hierarchy_reused = 0; }
+int emul_hierarchy_reused(void* s) { return ((EmulScene*)s)->hierarchy_reused; }
 void emul_set_regroup(void* s, int on) { ((EmulScene*)s)->regroup = on != 0; }   // for meshes added afterwards
 
 int emul_mesh_add(void* sp, const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes,
@@ -213,7 +218,8 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
         if (!M.empty) { boxes.push_back(instance_box(tfs[i], M.root_min, M.root_max)); ids.push_back((uint32_t)i); }
     }
     Tlas T;
-    TlasBuilder(boxes, ids, T).run();
+    if (s->keep_hierarchy) s->hierarchy_reused += s->standing.update(boxes, ids, (size_t)n_inst, T) ? 1 : 0;
+    else TlasBuilder(boxes, ids, T).run();
     if (tlas_pairs) *tlas_pairs = (int32_t)T.pairs.size();
     if (tlas_depth) *tlas_depth = T.depth;
     InstancedArgs I;

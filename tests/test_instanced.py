@@ -129,6 +129,68 @@ def test_thousands_of_instances_against_the_reference_loop(po, meshes, em_defaul
     assert got["tlas_depth"] <= 14 and len(np.unique(got["hit_inst"])) > 50
 
 
+def test_kept_hierarchy_follows_a_changing_list(po, meshes):
+    """The hierarchy over the instances is kept between frames and patched while few instances change: every frame
+    of a sequence -- one mover (the drone), several movers, a mesh swapped, an instance emptied and filled again,
+    nothing changed, most of the list moved (built anew), a shorter list -- equals the reference loop, and the kept
+    tree was reused where the change was small."""
+    s = emul.Scene()
+    for m in meshes:
+        assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+    e_post, e_nodes = po.build_bvh(np.zeros((0, 24), np.float32))
+    assert s.add(e_post, e_nodes, meshes[0].rgba) == 0, s.error()                          # mesh 3: no triangles
+    empty = po.HostMesh(np.ascontiguousarray(e_post, np.float32), e_nodes, meshes[0].rgba)
+    all_meshes = list(meshes) + [empty]
+    s.keep_hierarchy(True)
+    ids, tfs = grid_scene(po, 6, seed=3)
+    rng = np.random.default_rng(8)
+    w, h = 128, 72
+    cam, light = po.default_camera(), po.default_light()
+
+    def frame(ids, tfs):
+        fr, inst, tri = oracle_planes(po, all_meshes, ids, tfs, cam, light, w, h)
+        got = s.render_instanced(cam, light, ids, tfs, w, h)
+        check(got, fr, inst, tri)
+        return got
+
+    def somewhere():
+        return po.Transform(po.vec3(*(rng.uniform(-2.5, 2.5, 3) * [1, 0.2, 1] + [0, 0.9, 0])), po.vec3(0, float(rng.uniform(0, 6)), 0))
+
+    first = frame(ids, tfs)
+    assert s.hierarchy_reused() == 0
+    for f in (20, 30, 40):                                              # the drone flies: one mover per frame
+        tfs[0] = po.animation_transforms(f)[0]
+        got = frame(ids, tfs)
+        assert got["tlas_pairs"] == first["tlas_pairs"] + 1             # the kept tree and a join above it
+    assert s.hierarchy_reused() == 3
+    for k in (4, 9, 17, 30):                                            # several movers, one of them twice
+        tfs[k] = somewhere()
+    frame(ids, tfs)
+    tfs[9] = somewhere()
+    ids[12] = 0                                                         # a treasure becomes a drone
+    frame(ids, tfs)
+    ids[6] = 3                                                          # an instance loses its triangles ...
+    got = frame(ids, tfs)
+    assert not (got["hit_inst"] == 6).any()
+    ids[6] = 1                                                          # ... and gets them back
+    got = frame(ids, tfs)
+    assert (got["hit_inst"] == 6).any()
+    frame(ids, tfs)                                                     # nothing changed
+    assert s.hierarchy_reused() == 8
+    for k in range(2, len(tfs), 2):                                     # half the list moves: built anew and kept
+        tfs[k] = somewhere()
+    frame(ids, tfs)
+    assert s.hierarchy_reused() == 8
+    tfs[0] = po.animation_transforms(50)[0]
+    got = frame(ids, tfs)
+    assert s.hierarchy_reused() == 9
+    frame(ids[:11], tfs[:11])                                           # another length: built anew
+    assert s.hierarchy_reused() == 9
+    frame(ids[:11], tfs[:10] + [somewhere()])
+    assert s.hierarchy_reused() == 10
+    s.close()
+
+
 def test_no_instances_is_background(po, em_default):
     got = em_default.render_instanced(po.default_camera(), po.default_light(), [], [], 16, 9)
     assert (got["rgb"] == 50).all() and (got["hit_inst"] == -1).all() and (got["shadow"] == 255).all()
@@ -277,7 +339,7 @@ def test_gpu_reference_api_scene_with_repeated_meshes(po, meshes):
 
 @pytest.mark.gpu
 def test_gpu_successive_calls_with_partly_changed_lists(gscene, po, meshes):
-    """Placement constants are kept between calls for entries whose transform did not change: a sequence of
+    """Placement constants and the hierarchy over the instances are kept between calls: a sequence of
     calls on one context (some entries moved, a mesh swapped, the list shortened and lengthened, a different
     light) gives what the reference loop gives for each list."""
     import torch
@@ -301,6 +363,10 @@ def test_gpu_successive_calls_with_partly_changed_lists(gscene, po, meshes):
     steps.append((list(cur_ids), list(cur_tfs), 0))
     steps.append((list(cur_ids), list(cur_tfs), 1))                              # another light: every constant changes
     steps.append((list(ids), list(tfs), 0))
+    fly = list(tfs)
+    for f in (20, 30, 40):                                                       # one mover per frame: the kept hierarchy is patched
+        fly[0] = po.animation_transforms(f)[0]
+        steps.append((list(ids), list(fly), 0))
     for s_ids, s_tfs, li in steps:
         l = lights[li]
         light = capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
