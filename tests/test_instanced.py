@@ -191,6 +191,25 @@ def test_kept_hierarchy_follows_a_changing_list(po, meshes):
     s.close()
 
 
+def test_kept_hierarchy_stays_a_valid_tree_under_random_changes(tmp_path):
+    """tests/host_emul/tlas_check.cpp, built with the address and undefined-behaviour sanitizers: after every step of
+    random sequences (a few movers, emptied and refilled instances, many movers, other list lengths, no change) every
+    instance of the list hangs in exactly one reachable leaf and every box contains what is below it."""
+    import json
+    import os
+    import subprocess
+    from conftest import REPO
+    exe = str(tmp_path / "tlas_check")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-static-libasan", "-static-libubsan", "-o", exe, os.path.join(REPO, "tests", "host_emul", "tlas_check.cpp"), "-lm"], check=True, timeout=300)
+    for seed in (1, 2, 3):
+        r = subprocess.run([exe, str(seed), "400"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=0"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        assert info["errors"] == 0 and info["reused"] > 200
+
+
 def test_no_instances_is_background(po, em_default):
     got = em_default.render_instanced(po.default_camera(), po.default_light(), [], [], 16, 9)
     assert (got["rgb"] == 50).all() and (got["hit_inst"] == -1).all() and (got["shadow"] == 255).all()
