@@ -45,12 +45,14 @@ int main(int argc, char** argv) {
 
     static const char* names[3] = {"drone", "treasure", "ground"};
     Mesh meshes[3];
+    int loaded = 0, status = 0;
     for (int i = 0; i < 3; i++) {
         char obj[1024], tex[1024];
         snprintf(obj, sizeof obj, "%s/%s.obj", assets, names[i]);
         snprintf(tex, sizeof tex, "%s/%s.webp", assets, names[i]);
         meshes[i] = create_mesh(obj, tex);
-        if (meshes[i].triangle_count == 0) { fprintf(stderr, "cannot load %s\n", obj); return 1; }
+        loaded = i + 1;
+        if (meshes[i].triangle_count == 0) { fprintf(stderr, "cannot load %s\n", obj); status = 1; goto done; }
         add_mesh_to_scene(&scene, meshes[i]);
     }
     if (in_flight > 1) rt_host_set_frames_in_flight(in_flight);
@@ -63,17 +65,17 @@ int main(int argc, char** argv) {
         set_mesh_position(&scene.meshes[1], (Vec3){1.0f, 0.5f + 0.1f * sinf(t), 1.0f});
         set_mesh_rotation(&scene.meshes[1], (Vec3){0, t * 0.5f, 0});
         render_scene(&scene);
-        if (rt_host_last_status(&scene) != 0) { fprintf(stderr, "frame %d failed\n", frame); return 1; }
+        if (rt_host_last_status(&scene) != 0) { fprintf(stderr, "frame %d failed\n", frame); status = 1; goto done; }
         next_frame(&scene);
     }
-    if (rt_host_wait(&scene) != 0) return 1;
+    if (rt_host_wait(&scene) != 0) { status = 1; goto done; }
     const double t1 = seconds();
     if (ppm) {
         static const int which[3] = {0, 45, 95};
         for (int i = 0; i < 3; i++) {
             char name[1024];
             snprintf(name, sizeof name, "%s_%d.ppm", ppm, which[i]);
-            if (which[i] < scene.frame_count && rt_host_write_ppm(&scene, which[i], name) != 0) return 1;
+            if (which[i] < scene.frame_count && rt_host_write_ppm(&scene, which[i], name) != 0) { status = 1; goto done; }
         }
     }
     save_scene(&scene, out);
@@ -81,7 +83,8 @@ int main(int argc, char** argv) {
     printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"frames_in_flight\": %d, \"render_s\": %.4f, \"save_s\": %.4f}\n",
            scene.frame_count, scene.width, scene.height, in_flight, t1 - t0, t2 - t1);
 
-    for (int i = 0; i < 3; i++) destroy_mesh(&meshes[i]);
+done:
+    for (int i = 0; i < loaded; i++) destroy_mesh(&meshes[i]);
     destroy_scene(&scene);
-    return 0;
+    return status;
 }

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds the C-ABI library, the host library and examples/drone_animation.c with AddressSanitizer on the HOST side
+# only (device code is compiled as usual) into build/asan/, for a run on a GPU box:
+#     bash scripts/asan_driver.sh            (here, no GPU needed)
+#     ASAN_OPTIONS=detect_leaks=0 ./build/asan/drone_animation raytracer_amd/assets out.webp 4      (on the box)
+# The sanitizer runtime is the one of the ROCm clang, so all three pieces are compiled with it.
+set -eu
+cd "$(dirname "$0")/.."
+mkdir -p build/asan
+CL=/opt/rocm/lib/llvm/bin
+F="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt --offload-arch=gfx950 -Xarch_host -fsanitize=address"
+for f in rt_kernels.hip rt_upscale.hip rt_build.hip rt_host.cpp; do
+    (cd raytracer_amd/csrc && /opt/rocm/bin/hipcc $F -c $f -o ../../build/asan/${f%.*}.o)
+done
+cd build/asan
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Xarch_host -fsanitize=address -o librt_mi355.so rt_kernels.o rt_upscale.o rt_build.o rt_host.o
+rm -f ./*.o
+$CL/clang++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address -shared -I../../include -o libraytracer_host.so \
+    ../../raytracer_amd/host/raytracer_host.cpp ../../raytracer_amd/host/raytracer_math.cpp ../../raytracer_amd/host/webp_anim.cpp \
+    -pthread -L. -lrt_mi355 -ldl -lm -Wl,-rpath,'$ORIGIN'
+$CL/clang -std=c11 -O1 -g -fsanitize=address -D_POSIX_C_SOURCE=200809L -D_DEFAULT_SOURCE -I../../raytracer_amd/host -o drone_animation \
+    ../../examples/drone_animation.c -L. -lraytracer_host -Wl,-rpath,'$ORIGIN' -lm
+ls -la
