@@ -14,7 +14,12 @@ product:
 oracle:
 	$(MAKE) -C oracle
 
-emul: tests/host_emul/libemul.so
+emul: tests/host_emul/libemul.so tests/host_emul/abi_check
+
+# a C++ program that walks the whole C ABI on a GPU (run by tests/test_gpu_edges.py)
+tests/host_emul/abi_check: tests/host_emul/abi_check.cpp include/rt_mi355.h product
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -o $@ tests/host_emul/abi_check.cpp \
+	    -L raytracer_amd/csrc -lrt_mi355 -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../raytracer_amd/csrc' -Wl,-rpath,/opt/rocm/lib
 
 tests/host_emul/libemul.so: tests/host_emul/emul.cpp raytracer_amd/csrc/rt_pixel.h raytracer_amd/csrc/rt_sampled.h raytracer_amd/csrc/rt_instanced.h raytracer_amd/csrc/rt_bicubic.h raytracer_amd/csrc/rt_pack.h raytracer_amd/csrc/rt_exact.h raytracer_amd/csrc/rt_layout.h include/rt_mi355.h
 	$(CXX) -O2 -std=c++17 -ffp-contract=off -fopenmp -fPIC -shared -Wall -Wextra -o $@ tests/host_emul/emul.cpp -lm
@@ -30,6 +35,6 @@ clean:
 	$(MAKE) -C raytracer_amd/csrc clean
 	$(MAKE) -C raytracer_amd/host clean
 	$(MAKE) -C oracle clean
-	rm -f tests/host_emul/libemul.so examples/drone_animation
+	rm -f tests/host_emul/libemul.so tests/host_emul/abi_check examples/drone_animation
 
 .PHONY: all product oracle emul examples clean

@@ -3,6 +3,7 @@
 # only (device code is compiled as usual) into build/asan/, for a run on a GPU box:
 #     bash scripts/asan_driver.sh            (here, no GPU needed)
 #     ASAN_OPTIONS=detect_leaks=0 ./build/asan/drone_animation raytracer_amd/assets out.webp 4      (on the box)
+#     ASAN_OPTIONS=detect_leaks=0 ./build/asan/abi_check                                             (on the box)
 # The sanitizer runtime is the one of the ROCm clang, so all three pieces are compiled with it.
 set -eu
 cd "$(dirname "$0")/.."
@@ -20,4 +21,7 @@ $CL/clang++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address -shared
     -pthread -L. -lrt_mi355 -ldl -lm -Wl,-rpath,'$ORIGIN'
 $CL/clang -std=c11 -O1 -g -fsanitize=address -D_POSIX_C_SOURCE=200809L -D_DEFAULT_SOURCE -I../../raytracer_amd/host -o drone_animation \
     ../../examples/drone_animation.c -L. -lraytracer_host -Wl,-rpath,'$ORIGIN' -lm
+# a walk over the whole C ABI (tests/host_emul/abi_check.cpp), same sanitizer
+$CL/clang++ -O1 -g -std=c++17 -fsanitize=address -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I../../include -o abi_check \
+    ../../tests/host_emul/abi_check.cpp -L. -lrt_mi355 -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 ls -la

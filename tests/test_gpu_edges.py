@@ -200,3 +200,19 @@ def test_frames_in_flight_through_the_c_abi(capi, po, meshes):
     c.set_option("frames_in_flight", 1)
     assert np.array_equal(c.render_host(cam, light, conv(capi, placements[0]), *sizes[0], debug=False)[0], want[0])
     c.close()
+
+
+def test_c_abi_walk_through_from_a_compiled_program():
+    """tests/host_emul/abi_check.cpp (built by `make`): a C++ program on include/rt_mi355.h and the HIP runtime only --
+    uploads by every route, all kernel variants, batches, strips, sampled and instanced frames with changing lists,
+    rebuilt meshes, frames in flight into pinned and pageable memory, the upscale, refused arguments -- checks every
+    status and that the different routes to one frame give the same bytes."""
+    import json
+    import os
+    import subprocess
+    from conftest import REPO
+    exe = os.path.join(REPO, "tests", "host_emul", "abi_check")
+    assert os.path.exists(exe), "run `make`"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"errors": 0}
