@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds the C-ABI library, the host library and examples/drone_animation.c with AddressSanitizer on the HOST side
+# Builds the C-ABI library, the host library and examples/drone_animation.c with the address and undefined-behaviour sanitizers on the HOST side
 # only (device code is compiled as usual) into build/asan/, for a run on a GPU box:
 #     bash scripts/asan_driver.sh            (here, no GPU needed)
 #     ASAN_OPTIONS=detect_leaks=0 ./build/asan/drone_animation raytracer_amd/assets out.webp 4      (on the box)
@@ -9,19 +9,19 @@ set -eu
 cd "$(dirname "$0")/.."
 mkdir -p build/asan
 CL=/opt/rocm/lib/llvm/bin
-F="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt --offload-arch=gfx950 -Xarch_host -fsanitize=address"
+F="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt --offload-arch=gfx950 -Xarch_host -fsanitize=address,undefined"
 for f in rt_kernels.hip rt_upscale.hip rt_build.hip rt_host.cpp; do
     (cd raytracer_amd/csrc && /opt/rocm/bin/hipcc $F -c $f -o ../../build/asan/${f%.*}.o)
 done
 cd build/asan
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Xarch_host -fsanitize=address -o librt_mi355.so rt_kernels.o rt_upscale.o rt_build.o rt_host.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Xarch_host -fsanitize=address,undefined -o librt_mi355.so rt_kernels.o rt_upscale.o rt_build.o rt_host.o
 rm -f ./*.o
-$CL/clang++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address -shared -I../../include -o libraytracer_host.so \
+$CL/clang++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address,undefined -shared -I../../include -o libraytracer_host.so \
     ../../raytracer_amd/host/raytracer_host.cpp ../../raytracer_amd/host/raytracer_math.cpp ../../raytracer_amd/host/webp_anim.cpp \
     -pthread -L. -lrt_mi355 -ldl -lm -Wl,-rpath,'$ORIGIN'
-$CL/clang -std=c11 -O1 -g -fsanitize=address -D_POSIX_C_SOURCE=200809L -D_DEFAULT_SOURCE -I../../raytracer_amd/host -o drone_animation \
+$CL/clang -std=c11 -O1 -g -fsanitize=address,undefined -D_POSIX_C_SOURCE=200809L -D_DEFAULT_SOURCE -I../../raytracer_amd/host -o drone_animation \
     ../../examples/drone_animation.c -L. -lraytracer_host -Wl,-rpath,'$ORIGIN' -lm
 # a walk over the whole C ABI (tests/host_emul/abi_check.cpp), same sanitizer
-$CL/clang++ -O1 -g -std=c++17 -fsanitize=address -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I../../include -o abi_check \
+$CL/clang++ -O1 -g -std=c++17 -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I../../include -o abi_check \
     ../../tests/host_emul/abi_check.cpp -L. -lrt_mi355 -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 ls -la
