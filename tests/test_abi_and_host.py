@@ -95,7 +95,8 @@ def test_host_library_cpu_side_under_sanitizers(host, tmp_path):
     """tests/host_emul/host_check.cpp compiled together with the host library's sources under the address and
     undefined-behaviour sanitizers: the OBJ reader in both modes on the assets, on malformed files and on randomly
     damaged copies of a real file; unreadable textures; the BVH build on tiny, degenerate and non-finite input; the
-    animation writer.  No invalid access, no undefined operation, no leak, and the program's own checks hold."""
+    animation writer.  No invalid access, no undefined operation, no leak, no data race (second build, thread sanitizer), and the
+    program's own checks hold."""
     src = os.path.join(REPO, "raytracer_amd", "host")
     exe = str(tmp_path / "host_check")
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
@@ -109,6 +110,18 @@ def test_host_library_cpu_side_under_sanitizers(host, tmp_path):
     r = subprocess.run([exe, host.ASSETS, str(scratch)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=1"))
     assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip().splitlines()[-1] == '{"errors": 0}'
+    # the same program under the thread sanitizer: the animation writer encodes on worker threads
+    exe_t = str(tmp_path / "host_check_tsan")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=thread", "-I", os.path.join(REPO, "include"), "-o", exe_t,
+                    os.path.join(REPO, "tests", "host_emul", "host_check.cpp"), os.path.join(src, "raytracer_host.cpp"),
+                    os.path.join(src, "raytracer_math.cpp"), os.path.join(src, "webp_anim.cpp"), "-pthread",
+                    "-L", os.path.join(REPO, "raytracer_amd", "csrc"), "-lrt_mi355", "-ldl", "-lm",
+                    "-Wl,-rpath," + os.path.join(REPO, "raytracer_amd", "csrc")], check=True, timeout=600)
+    r = subprocess.run([exe_t, host.ASSETS, str(scratch)], capture_output=True, text=True, timeout=900)
+    if "FATAL: ThreadSanitizer" in r.stderr and "unexpected memory mapping" in r.stderr:
+        pytest.skip("the thread sanitizer cannot map its shadow memory on this kernel")
+    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
     assert r.stdout.strip().splitlines()[-1] == '{"errors": 0}'
 
 
