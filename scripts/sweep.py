@@ -49,7 +49,7 @@ def main():
     bufs = [torch.empty((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(8)]
     times = {c: {f: [] for f in frames} for c in configs}
     same = {c: True for c in configs}
-    for r in range(a.rounds + 1):                         # round 0 = warm-up + parity check
+    for r in range(a.rounds + 1):                         # first pass = warm-up + parity check
         for c in configs:
             try:
                 ctx.set_option("variant", c[0])
