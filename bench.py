@@ -4,47 +4,56 @@ ground scene at 1920x1080, one ray per pixel plus one shadow ray per hit pixel.
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one frame.  Rank r of N renders frames r, r+N, r+2N, ... of the 96-frame animation
-(per-GPU work is fixed as N grows: weak scaling).  Frames are submitted `--batch` at a time
-through rt_render_frames (one launch per batch: the long-running tiles of every frame in the batch
-overlap with the bulk of the others); for N > 1 each finished batch of RGB8 framebuffers is
-gathered to rank 0 over RCCL inside the timed region while the next batch renders.  Framebuffers
-stay in HBM; nothing is copied to the host inside the timed region.  Before the W warm-up steps every
-rank keeps its GPU busy with 24 untimed launches (the batches of the timed region in turn), so that the
-short timed region runs at the clocks a long render would see.
+A step is one frame.  Rank r of N owns frames r, r+N, r+2N, ... of the 96-frame animation (per-GPU
+work is fixed as N grows: weak scaling).  Step k of a rank renders entry (7 k) mod L of its L own
+frames: 7 is coprime to every share length, so ANY number of steps is an even sample of the whole
+animation and the value does not depend on --steps or --warmup (frames differ by 2x in cost).
+Frames are submitted `--batch` at a time through rt_render_frames (one launch per batch: the
+long-running tiles of every frame in the batch overlap with the bulk of the others); for N > 1 each
+finished batch of RGB8 framebuffers is gathered to rank 0 (torch.distributed: RCCL with the default
+--backend nccl) inside the timed region while the next batch renders.  Framebuffers stay in HBM;
+nothing is copied to the host inside the timed region.  Before the W warm-up steps every rank keeps
+its GPU busy with 24 untimed launches, so that the short timed region runs at working clocks.
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this program starts its own N ranks (a
+child `python -m torch.distributed.run`, before anything in this process has touched a GPU) and
+relays rank 0's JSON line; under torch.distributed.run it is one of the ranks.
 
 A ray is one camera ray or one shadow ray tested against the whole scene (all meshes):
 rays per frame = pixels + pixels that hit something.
 
 Rank 0 prints one JSON line.  Besides the throughput it carries
-  roofline      the render kernel against the HBM roofline: algorithmic bytes of the reference's
-                traversal (32 B per box test, 36 B per triangle test, 64 B per hit pixel for
-                attributes + texel, 3 B per pixel stored) over the kernel's mean duration measured
-                with HIP events on its stream; plus the same for FP32 VALU work
+  roofline      the render kernel against the roof that binds it, FP32 vector issue: algorithmic
+                FLOPs of the reference's traversal (22 per box test, 50 per triangle test, 45 per
+                ray and mesh for the transform) over the kernel's mean duration measured with HIP
+                events on its stream, against the 157.3 TFLOP/s vector peak.  `traffic` is HBM bytes
+                per launch from a separate rocprofv3 --pmc pass (profiles/), `hbm_frac` the
+                resulting share of the 8 TB/s HBM peak; the algorithmic bytes are served by L1/L2.
   cpu_baseline  the compiled reference functions (or, without them, the CPU restatement) timed on
                 the host cores on a bounded sample of the same workload (N = 1, rank 0 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-VALU_PEAK_TFLOPS = 157.3       # MI355X FP32 vector peak
+VALU_PEAK_TFLOPS = 157.3       # MI355X FP32 vector peak (packed FMA on every lane)
 # Algorithmic bytes / flops of the reference's traversal.
 B_SLAB, B_TRI, B_HIT, B_PIXEL = 32, 36, 64, 3
 F_SLAB, F_TRI, F_XFORM = 22, 50, 45
+FRAME_STRIDE = 7               # step k renders entry (7 k) mod L of the rank's L frames
+SETTLE = 24                    # untimed launches before the warm-up
+PMC_PROFILE = os.path.join(REPO, "profiles", "r2_traffic.json")
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=96)
@@ -58,12 +67,50 @@ def parse():
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     p.add_argument("--one-device", action="store_true",
                    help="rehearsal on a one-GPU machine: every rank uses GPU 0 (use with --backend gloo)")
+    p.add_argument("--rehearse-cpu", action="store_true",
+                   help="no GPU and no rendering: frames are byte patterns in host memory (forces --backend gloo).  "
+                        "Exercises rank start-up, frame dealing, the gathers and their check; its value is not a measurement")
     p.add_argument("--cpu-frames", type=int, default=8)
-    return p.parse_args()
+    p.add_argument("--master-port", type=int, default=0, help="rendezvous port when this program starts its own ranks (0 = a free one)")
+    return p.parse_args(argv)
+
+
+def frame_sequence(share, n):
+    """Frames of steps 0..n-1 of a rank that owns `share`."""
+    return [share[(k * FRAME_STRIDE) % len(share)] for k in range(n)]
+
+
+def spawn_ranks(a, argv):
+    """Starts N ranks of this program under torch.distributed.run as a child process and relays rank 0's
+    JSON line.  Nothing in this process has initialised a GPU (torch is not even imported here), and the
+    children are fresh interpreters."""
+    port = a.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        sys.exit(f"bench.py: the {a.gpus}-rank run failed (torch.distributed.run exit code {proc.returncode})")
+    if line is None:
+        sys.exit("bench.py: the ranks finished without a result line")
+    print(line, flush=True)
 
 
 def cpu_baseline(width, height, n_frames):
-    """Times the CPU path on the host cores: frames 0..n-1 of the animation at the bench size."""
+    """Times the CPU path on the host cores: an even sample of n_frames animation frames at the bench size."""
     from oracle import pyoracle as po
     meshes = po.default_meshes()
     cam, light = po.default_camera(), po.default_light()
@@ -77,34 +124,64 @@ def cpu_baseline(width, height, n_frames):
         threads = po.lib().orc_max_threads()
         run = lambda f: po.render_frame(meshes, po.animation_transforms(f), cam, light, width, height)   # noqa: E731
     run(0)                                                   # warm-up
+    frames = [(k * 96) // n_frames for k in range(n_frames)]
     rays, t0 = 0, time.perf_counter()
-    for f in range(n_frames):
+    for f in frames:
         fr = run(f)
         rays += width * height + int((fr.hit_id >= 0).sum())
     dt = time.perf_counter() - t0
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(threads),
             "kind": "reference" if use_ref else "port",
-            "sample": f"frames 0..{n_frames - 1} of the animation at {width}x{height}, "
+            "sample": f"frames {frames} of the animation at {width}x{height}, "
                       f"{'compiled reference functions (gcc -O3 -ffp-contract=off) + composition loop' if use_ref else 'CPU restatement'}, "
                       f"OpenMP dynamic rows, {threads} threads, {dt:.1f} s",
             "ms_per_frame": round(dt / n_frames * 1e3, 2)}
 
 
+class PatternScene:
+    """--rehearse-cpu: stands in for the renderer with byte patterns, so that the multi-rank flow runs without a GPU."""
+
+    def __init__(self):
+        self.ctx = None
+
+    @staticmethod
+    def fill(frames, out):
+        for k, f in enumerate(frames):
+            out[k].fill_((37 * f + 11) % 251)
+
+    def render_frames(self, frames, W, H, out, stream=None):
+        self.fill(frames, out)
+
+    def close(self):
+        pass
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return spawn_ranks(a, argv)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
-    if not torch.cuda.is_available():
+    a.gpus = world
+    rehearse = a.rehearse_cpu
+    if rehearse:
+        a.backend = "gloo"
+    elif not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the rendering core has no CPU path")
     if a.one_device:
         local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if rehearse:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -115,63 +192,72 @@ def main():
         if a.verbose:
             print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
-    from raytracer_amd import demo, sharding
-    scene = demo.DemoScene(local)           # its loader's printf lines go to stderr: stdout is kept for the one JSON line
-    say("scene loaded")
-    ctx = scene.ctx
-    if a.block:
-        ctx.set_option("block", a.block)
-    W, H = a.width, a.height
-    NF = demo.N_FRAMES
-    # An explicit stream, made torch's current one: the kernels are launched on it, and RCCL orders
-    # its gathers after the work already queued on the current stream.
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    sptr = stream.cuda_stream
+    def device_sync():
+        if not rehearse:
+            torch.cuda.synchronize(dev)
 
-    # frames this rank renders, in order; wraps around the animation if steps exceed its share
+    from raytracer_amd import sharding
+    W, H = a.width, a.height
+    if rehearse:
+        scene, ctx, NF, sptr, stream = PatternScene(), None, 96, None, None
+    else:
+        from raytracer_amd import capi, demo
+        scene = demo.DemoScene(local)       # its loader's printf lines go to stderr: stdout is kept for the one JSON line
+        ctx = scene.ctx
+        if a.block:
+            ctx.set_option("block", a.block)
+        NF = demo.N_FRAMES
+        # An explicit stream, made torch's current one: the kernels are launched on it, and RCCL orders
+        # its gathers after the work already queued on the current stream.
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        sptr = stream.cuda_stream
+    say("scene loaded")
+
+    # frames of this rank's timed steps (independent of --warmup) and of its warm-up steps
     share = sharding.frames_for_rank(NF, rank, world) or [rank % NF]
-    seq = [share[i % len(share)] for i in range(a.warmup + a.steps)]
+    seq = frame_sequence(share, a.steps)
+    warm = frame_sequence(share, a.steps + a.warmup)[a.steps:]
 
     # ---- untimed: rays and reference-equivalent work of every distinct frame of this rank
-    hit_id = torch.empty((H, W), dtype=torch.int32, device=dev)
-    scratch = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
     info, own = {}, {}
-    from raytracer_amd import capi
-    for f in sorted(set(seq[a.warmup:])):
-        scene.render(f, W, H, scratch, hit_id=hit_id, flags=capi.RT_FLAG_COUNT_WORK | capi.RT_FLAG_REFERENCE_ORDER, stream=sptr)
-        stream.synchronize()
-        info[f] = ctx.last_counters()                       # the reference's traversal: every box it would test
-        assert info[f]["hit_pixels"] == int((hit_id >= 0).sum().item())
-        scene.render(f, W, H, scratch, flags=capi.RT_FLAG_COUNT_WORK, stream=sptr)
-        stream.synchronize()
-        own[f] = ctx.last_counters()                        # the traversal the timed kernel runs (ordered, culled)
-    ctx.set_option("timing", 0)
+    if rehearse:
+        for f in set(seq):
+            info[f] = {"primary_rays": W * H, "shadow_rays": 0}
+    else:
+        hit_id = torch.empty((H, W), dtype=torch.int32, device=dev)
+        scratch = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        for f in sorted(set(seq)):
+            scene.render(f, W, H, scratch, hit_id=hit_id, flags=capi.RT_FLAG_COUNT_WORK | capi.RT_FLAG_REFERENCE_ORDER, stream=sptr)
+            stream.synchronize()
+            info[f] = ctx.last_counters()                       # the reference's traversal: every box it would test
+            assert info[f]["hit_pixels"] == int((hit_id >= 0).sum().item())
+            scene.render(f, W, H, scratch, flags=capi.RT_FLAG_COUNT_WORK, stream=sptr)
+            stream.synchronize()
+            own[f] = ctx.last_counters()                        # the traversal the timed kernel runs (ordered, culled)
+        ctx.set_option("timing", 0)
     say("work counted")
 
     # ---- warm-up
     nb = (a.steps + a.batch - 1) // a.batch
+    batches = [seq[b * a.batch:min((b + 1) * a.batch, a.steps)] for b in range(nb)]
     RING = 4                                                   # batches in flight: send buffers and gathers
     bufs = [torch.empty((a.batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(min(nb, RING))]
-    with torch.cuda.stream(stream):
-        for buf in bufs:                                       # first touch of every output buffer happens here, untimed
-            buf.zero_()
+    for buf in bufs:                                           # first touch of every output buffer happens here, untimed
+        buf.zero_()                                            # (on the current stream = the render stream)
     # The timed region of the default run lasts some 15 ms, less than the GPU needs to reach its working clocks
-    # after the synchronous frame-by-frame counting above (measured: 0.166 ms per step straight after it, 0.157 ms
-    # from about 100 frames on).  So the GPU is kept busy for a fixed number of untimed launches first, whatever
-    # --warmup says; the W warm-up steps proper follow.
-    SETTLE = 24
-    for k in range(SETTLE):                                     # the launches of the timed region, in turn
-        b = k % nb
-        scene.render_frames(seq[a.warmup + b * a.batch:a.warmup + min((b + 1) * a.batch, a.steps)], W, H, bufs[k % len(bufs)], stream=sptr)
+    # after the synchronous frame-by-frame counting above.  So the GPU is kept busy for a fixed number of untimed
+    # launches first, whatever --warmup says; the W warm-up steps proper follow.
+    if not rehearse:
+        for k in range(SETTLE):                                 # the launches of the timed region, in turn
+            scene.render_frames(batches[k % nb], W, H, bufs[k % len(bufs)], stream=sptr)
     for k, i in enumerate(range(0, a.warmup, a.batch)):
-        fr = seq[i:min(i + a.batch, a.warmup)]
-        scene.render_frames(fr, W, H, bufs[k % len(bufs)], stream=sptr)
+        scene.render_frames(warm[i:min(i + a.batch, a.warmup)], W, H, bufs[k % len(bufs)], stream=sptr)
     if world > 1:
         g = sharding.FrameGather(rank, world)
         g.submit(bufs[0])
         g.finish()
-    torch.cuda.synchronize(dev)
+    device_sync()
     say("warm-up rendered and gathered")
     if world > 1:
         dist.barrier()
@@ -182,57 +268,60 @@ def main():
     if gather is not None:
         gather.prealloc(nb, bufs[0])
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    device_sync()
     t0 = time.perf_counter()
     for b in range(nb):
-        fr = seq[a.warmup + b * a.batch:a.warmup + min((b + 1) * a.batch, a.steps)]
-        scene.render_frames(fr, W, H, bufs[b % len(bufs)], stream=sptr)
+        scene.render_frames(batches[b], W, H, bufs[b % len(bufs)], stream=sptr)
         if gather is not None:
             gather.submit(bufs[b % len(bufs)])
     if gather is not None:
         gather.finish()
-    torch.cuda.synchronize(dev)
+    device_sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     say(f"timed region done in {dt:.4f} s")
 
-    rays_rank = sum(info[f]["primary_rays"] + info[f]["shadow_rays"] for f in seq[a.warmup:])
-    stats = torch.tensor([dt, float(rays_rank)], dtype=torch.float64, device=dev)
+    rays_rank = sum(info[f]["primary_rays"] + info[f]["shadow_rays"] for f in seq)
     if world > 1:
+        stats = torch.tensor([dt, float(rays_rank)], dtype=torch.float64, device=dev)
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rsum = stats[1:].clone()
         dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
         dt_all, rays_all = float(tmax.item()), float(rsum.item())
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, "cpu" if rehearse else f"cuda:{local}")
     else:
         dt_all, rays_all = dt, float(rays_rank)
+        rank_devices = ["cpu" if rehearse else f"cuda:{local}"]
 
     # ---- untimed: what arrives on rank 0 is what the ranks rendered.  Every rank sends the first batch of its
-    # share once more; rank 0 renders the same frames itself and compares the bytes.
+    # timed steps once more; rank 0 renders the same frames itself and compares the bytes.
     gather_ok = None
     if world > 1:
         def first_batch(r):
             sh = sharding.frames_for_rank(NF, r, world) or [r % NF]
-            return [sh[i % len(sh)] for i in range(a.batch)]
+            fr = frame_sequence(sh, a.batch)
+            return fr
         scene.render_frames(first_batch(rank), W, H, bufs[0], stream=sptr)
         g = sharding.FrameGather(rank, world)
         g.submit(bufs[0])
         got = g.finish()
-        torch.cuda.synchronize(dev)
+        device_sync()
         if rank == 0:
             mine = torch.empty_like(bufs[0])
             gather_ok = True
             for r in range(world):
                 scene.render_frames(first_batch(r), W, H, mine, stream=sptr)
-                stream.synchronize()
+                device_sync()
                 gather_ok = gather_ok and bool(torch.equal(mine, got[0][r].to(dev)))
         say(f"gather verified: {gather_ok}")
 
     # ---- kernel duration with HIP events on the launch stream (rank 0): the same launches as the
     # timed region, one at a time
     roof, single_ms = None, None
-    if rank == 0:
+    if rank == 0 and not rehearse:
         ctx.set_option("timing", 1)
 
         def work(c):
@@ -240,52 +329,54 @@ def main():
             return (c["slab_tests"] * B_SLAB + c["tri_tests"] * B_TRI + c["hit_pixels"] * B_HIT + W * H * B_PIXEL,
                     c["slab_tests"] * F_SLAB + c["tri_tests"] * F_TRI + rays * 3 * F_XFORM)
         ms, alg_bytes, alg_flops, own_bytes, own_flops = [], [], [], [], []
-        for b in range(nb):
-            fr = seq[a.warmup + b * a.batch:a.warmup + min((b + 1) * a.batch, a.steps)]
+        for fr in batches:
             scene.render_frames(fr, W, H, bufs[0], stream=sptr)
             ms.append(ctx.last_kernel_ms())
             alg_bytes.append(sum(work(info[f])[0] for f in fr)); alg_flops.append(sum(work(info[f])[1] for f in fr))
             own_bytes.append(sum(work(own[f])[0] for f in fr)); own_flops.append(sum(work(own[f])[1] for f in fr))
         kern_ms = float(np.mean(ms))
-        gbs = float(np.mean(alg_bytes)) / (kern_ms * 1e-3) / 1e9
-        tfl = float(np.mean(alg_flops)) / (kern_ms * 1e-3) / 1e12
-        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        secs = kern_ms * 1e-3
+        tfl = float(np.mean(alg_flops)) / secs / 1e12
+        roof = {"bound": "valu", "achieved": round(tfl, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tfl / VALU_PEAK_TFLOPS, 5), "traffic": None, "hbm_frac": None,
                 "kernel": "render_batch (block %d), %d frames per launch" % (ctx.get_option("block"), a.batch),
-                "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(np.mean(alg_bytes)),
-                "basis": "reference-equivalent traversal (every box and triangle test scene.c/bvh.c would run)",
-                "valu": {"achieved": round(tfl, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tfl / VALU_PEAK_TFLOPS, 5)},
-                "kernel_counted": {"bytes_per_launch": int(np.mean(own_bytes)),
-                                   "GB/s": round(float(np.mean(own_bytes)) / (kern_ms * 1e-3) / 1e9, 1),
-                                   "TFLOP/s": round(float(np.mean(own_flops)) / (kern_ms * 1e-3) / 1e12, 3),
+                "kernel_ms": round(kern_ms, 4), "algorithmic_flops_per_launch": int(np.mean(alg_flops)),
+                "basis": "FLOPs of the reference-equivalent traversal (every box and triangle test scene.c/bvh.c would run: 22 per box "
+                         "test, 50 per triangle test, 45 per ray and mesh) over the kernel's mean HIP-event duration; the peak assumes "
+                         "packed FMAs on every lane, the bit-exact build issues neither (one rounding per reference operation)",
+                "algorithmic_bytes_per_launch": int(np.mean(alg_bytes)),
+                "cache_served_GBs": round(float(np.mean(alg_bytes)) / secs / 1e9, 1),
+                "kernel_counted": {"flops_per_launch": int(np.mean(own_flops)), "bytes_per_launch": int(np.mean(own_bytes)),
+                                   "TFLOP/s": round(float(np.mean(own_flops)) / secs / 1e12, 3),
                                    "basis": "tests the ordered, distance-culled traversal of the kernel executes"},
-                "note": "the scene (150 KB of nodes, 170 KB of triangles) is cache resident: these bytes are served by "
-                        "L1/L2, not HBM; the kernel is bound by FP32 VALU issue under divergence"}
+                "note": "the scene (150 KB of nodes, 170 KB of triangles) is cache resident: the algorithmic bytes are served by "
+                        "L1/L2 (cache_served_GBs), HBM carries the framebuffers and texels only"}
         # one frame launched alone (its duration is set by its slowest tiles)
         one = []
-        for f in sorted(set(seq[a.warmup:]))[:8]:
+        for f in sorted(set(seq))[:8]:
             scene.render(f, W, H, bufs[0][0], stream=sptr)
             one.append(ctx.last_kernel_ms())
         single_ms = round(float(np.mean(one)), 4)
-        tr = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tr):
-            try:                                              # counters of an earlier rocprofv3 --pmc run (scripts/gpu_pmc.sh)
-                pmc = json.load(open(tr))
-                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
-                roof["traffic_note"] = "HBM bytes per %s launch of 8 frames from FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, profiles/traffic.json" % pmc.get("kernel")
-                roof["valu"]["issue_utilisation_pmc"] = pmc.get("valu_issue_utilisation")
-                roof["valu"]["lane_utilisation_pmc"] = pmc.get("valu_lane_utilisation")
-                roof["binding"] = "FP32 VALU issue: %.0f %% of issue cycles busy, %.0f %% of lanes active (counters of an earlier run)" % (
-                    100.0 * pmc.get("valu_issue_utilisation", 0.0), 100.0 * pmc.get("valu_lane_utilisation", 0.0))
+        if os.path.exists(PMC_PROFILE):
+            try:        # counters of a separate rocprofv3 --pmc pass over this same command (scripts/gpu_pmc.sh), per launch
+                pmc = json.load(open(PMC_PROFILE))
+                hbm = pmc.get("hbm_bytes_per_launch")
+                roof["traffic"] = hbm
+                if hbm:
+                    roof["hbm_frac"] = round(hbm / secs / 1e9 / HBM_PEAK_GBS, 5)
+                roof["traffic_source"] = ("profiles/%s: FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per %s launch of 8 frames, separate "
+                                          "--pmc pass, not the timed launches" % (os.path.basename(PMC_PROFILE), pmc.get("kernel")))
+                roof["valu_issue_utilisation_pmc"] = pmc.get("valu_issue_utilisation")
+                roof["valu_lane_utilisation_pmc"] = pmc.get("valu_lane_utilisation")
             except Exception:
                 pass
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not rehearse:
         cpu = cpu_baseline(W, H, a.cpu_frames)
 
     if rank == 0:
+        transport = {"nccl": "RCCL", "gloo": "gloo (host memory)"}.get(a.backend, a.backend)
         out = {
             "metric": "Mrays/s (primary+shadow), 1080p drone scene",
             "value": round(rays_all / dt_all / 1e6, 2),
@@ -295,8 +386,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "reference scene assets (drone/treasure/ground OBJ + WebP), animation frames of raytracer.c",
             "config": {"workload": f"{W}x{H} frame, 1 primary ray/pixel + 1 shadow ray/hit pixel, 3 meshes (3625 triangles)",
-                       "frames_per_rank": a.steps, "frames_per_launch": a.batch, "untimed_settling_launches": 24, "sharding": "frame f on rank f mod N" if world > 1 else "single GPU",
-                       "gather": f"RGB8 framebuffers to rank 0 over RCCL, {a.batch} frames per message" if world > 1 else "none",
+                       "frames": f"step k of a rank renders entry ({FRAME_STRIDE} k) mod L of its L frames of the 96-frame animation: "
+                                 "an even sample of the animation for any --steps",
+                       "frames_per_rank": a.steps, "frames_per_launch": a.batch, "untimed_settling_launches": SETTLE,
+                       "sharding": "frame f on rank f mod N" if world > 1 else "single GPU",
+                       "gather": f"RGB8 framebuffers to rank 0 over {transport}, {a.batch} frames per message" if world > 1 else "none",
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": (dist.get_backend() if world > 1 else None),
+                       "rank_devices": rank_devices,
                        "gathered_frames_equal_rank0_render": gather_ok},
             "frames_per_s": round(a.steps * world / dt_all, 2),
             "rays_per_frame": int(rays_rank / a.steps),
@@ -304,6 +401,9 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if rehearse:
+            out["rehearsal"] = "cpu: no GPU, no rendering, frames are byte patterns -- value is not a measurement"
+            out["data"] = "byte patterns"
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:

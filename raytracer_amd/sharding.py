@@ -106,17 +106,25 @@ def render_sharded(n_frames: int, rank: int, world: int, height: int, width: int
     render_one(frame_index, out[H,W,3] uint8 on `device`) enqueues one frame.  Ranks with fewer
     frames than others pad their last batch with frames that rank 0 discards, so that every rank
     issues the same collectives.  Returns on rank 0 a dict frame -> tensor [H,W,3]; None elsewhere.
+
+    On a GPU everything here is ordered by torch's CURRENT stream: the padding is cleared on it and the
+    gather is queued behind it, so render_one must launch on that stream too (pass
+    torch.cuda.current_stream().cuda_stream as the `stream` argument of the rendering call) -- a
+    frame rendered on another stream could be overtaken by the gather that sends it.
     """
     mine = frames_for_rank(n_frames, rank, world)
     per_rank = (n_frames + world - 1) // world            # the longest share
     n_batches = (per_rank + batch - 1) // batch
     g = FrameGather(rank, world, group)
     for b in range(n_batches):
-        buf = torch.zeros((batch, height, width, 3), dtype=torch.uint8, device=device)
+        # no fill of the whole buffer: every slot is written exactly once, by the render or by the padding
+        buf = torch.empty((batch, height, width, 3), dtype=torch.uint8, device=device)
         for k in range(batch):
             i = b * batch + k
             if i < len(mine):
                 render_one(mine[i], buf[k])
+            else:
+                buf[k].zero_()
         g.submit(buf)
     got = g.finish()
     if rank != 0:

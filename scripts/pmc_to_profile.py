@@ -2,7 +2,7 @@
 """Condenses the counter passes of scripts/gpu_pmc.sh into one JSON file that bench.py reads for
 the `traffic` and VALU figures of its roofline object.
 
-    python scripts/pmc_to_profile.py gpurun_out/pmc_batch8 render_batch profiles/traffic.json
+    python scripts/pmc_to_profile.py gpurun_out/pmc_bench render_batch profiles/r2_traffic.json
 
 HBM bytes per launch: FETCH_SIZE and WRITE_SIZE are reported in KiB and were collected in separate
 passes.  On gfx950 FETCH_SIZE counts 64 B for every memory-side read request although wide requests

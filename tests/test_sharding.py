@@ -231,3 +231,53 @@ def test_gather_frame_two_ranks_gloo(height):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+# ------------------------------------------------------------------ bench.py as a plain command
+def _run_bench(*args, timeout=240):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + list(args), stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout, env=env)
+
+
+def test_bench_starts_its_own_ranks_when_given_a_gpu_count():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the program starts two ranks itself
+    (here on byte patterns over gloo, no GPU), rank 0's JSON line comes back through the parent."""
+    import json
+    r = _run_bench("--gpus", "2", "--rehearse-cpu", "--steps", "8", "--warmup", "2", "--width", "64", "--height", "36", "--batch", "4")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["config"]["rank_devices"] == ["cpu", "cpu"]
+    assert out["config"]["gathered_frames_equal_rank0_render"] is True
+    assert "rehearsal" in out and out["steps"] == 8 and out["scaling"] == "weak"
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    """Without a GPU the ranks refuse to run (there is no CPU rendering path); the parent must not exit 0."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--steps", "8", "--warmup", "0")
+    assert r.returncode != 0
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_bench_frame_sequence_does_not_depend_on_the_step_count():
+    sys.path.insert(0, REPO)
+    import bench
+    from raytracer_amd.sharding import frames_for_rank
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            share = frames_for_rank(96, rank, world)
+            full = bench.frame_sequence(share, len(share))
+            assert sorted(full) == share                                  # one pass visits every frame of the share once
+            for n in (5, 20, 96):
+                assert bench.frame_sequence(share, n) == bench.frame_sequence(share, 200)[:n]
+    # twenty steps of one GPU spread over the whole animation, not its first quarter
+    twenty = bench.frame_sequence(list(range(96)), 20)
+    assert min(twenty) < 10 and max(twenty) > 85 and len(set(f // 24 for f in twenty)) == 4
