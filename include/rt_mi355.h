@@ -165,6 +165,20 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light
                      const rt_transform* transforms, int32_t n_frames, int32_t n_transforms,
                      int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream);
 
+/* rt_render_frames for callers that cannot allocate device memory while they render (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments, same launch, same bytes as rt_render_frames, but the call reaches no allocator: the per-frame constants
+ * that rt_render_frames stages in a device buffer of the context go through a file-scope device array of the library
+ * (RT_MAX_BATCH records, 31 616 bytes, held by every GPU the library runs on until the process ends; its address on the
+ * context's GPU is looked up by rt_ctx_create).  Conditions: n_frames <= RT_MAX_BATCH (more: RT_ERR_CAPACITY), and
+ * the mesh list must not have changed since the last rendering call of this context -- that call put the combined
+ * node array on the device; otherwise RT_ERR_UNSUPPORTED and nothing is launched.  All calls on one GPU share the
+ * array: calls that overlap on one GPU (different streams, or contexts on the same device) race; calls on one stream
+ * are ordered.  Every byte the kernel reads from the array is written by the call itself first. */
+int rt_render_frames_noalloc(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
+                             const rt_transform* transforms, int32_t n_frames, int32_t n_transforms,
+                             int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream);
+
 /* Beyond the reference (it has one ray through the pixel centre, scene.c:61-62, and one light, scene.h:17):
  * samples_per_pixel jittered camera rays per pixel and n_lights directional lights, every per-ray
  * operation as in render_scene.  Sample s of pixel (x,y) goes through (x+jx, y+jy) with (jx,jy) = (0.5,0.5)

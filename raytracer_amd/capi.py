@@ -62,7 +62,7 @@ EXPORTS = [
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
-    "rt_render_frame_sampled", "rt_render_frame_instanced", "rt_render_frame_instanced_host",
+    "rt_render_frame_sampled", "rt_render_frame_instanced", "rt_render_frame_instanced_host", "rt_render_frames_noalloc",
 ]
 
 _lib = None
@@ -116,6 +116,7 @@ def lib():
                                            vp, vp, vp, vp]
         L.rt_render_frames.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, i32,
                                        vp, C.c_size_t, vp]
+        L.rt_render_frames_noalloc.argtypes = L.rt_render_frames.argtypes
         L.rt_render_frame_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, i32, i32,
                                               u32, u32, vp, vp, vp]
         L.rt_strip_rows.argtypes = [i32, i32, i32]
@@ -285,9 +286,10 @@ class Context:
                                           _dev_ptr(shadow), stream))
 
     def render_frames(self, camera: Camera, light: Light, transforms: Sequence[Sequence[Transform]], width: int, height: int,
-                      rgb, frame_stride: Optional[int] = None, stream: Optional[int] = None):
+                      rgb, frame_stride: Optional[int] = None, stream: Optional[int] = None, noalloc: bool = False):
         """rt_render_frames: transforms[f] are the placements of frame f; frame f lands at rgb + f*frame_stride
-        (default: images back to back, i.e. a [n_frames, height, width, 3] uint8 tensor)."""
+        (default: images back to back, i.e. a [n_frames, height, width, 3] uint8 tensor).
+        noalloc=True calls rt_render_frames_noalloc (same result, no device allocation inside the call)."""
         n = len(transforms)
         m = len(transforms[0]) if n else 0
         flat = [t for frame in transforms for t in frame]
@@ -295,8 +297,8 @@ class Context:
             raise ValueError("every frame needs the same number of transforms")
         arr = (Transform * max(len(flat), 1))(*flat)
         stride = int(frame_stride) if frame_stride is not None else int(width) * int(height) * 3
-        self._check(lib().rt_render_frames(self._h, C.byref(camera), C.byref(light), arr, n, m, int(width), int(height),
-                                           _dev_ptr(rgb), stride, stream))
+        entry = lib().rt_render_frames_noalloc if noalloc else lib().rt_render_frames
+        self._check(entry(self._h, C.byref(camera), C.byref(light), arr, n, m, int(width), int(height), _dev_ptr(rgb), stride, stream))
 
     def render_host(self, camera: Camera, light: Light, transforms: Sequence[Transform], width: int, height: int,
                     debug: bool = True, flags: int = 0):

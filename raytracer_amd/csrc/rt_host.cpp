@@ -298,7 +298,8 @@ void fill_frame(const rt_ctx* ctx, const rt_camera& camera, const rt_light& ligh
 // First tile row (8-pixel rows) of the screen area in which a ray of this frame, primary or
 // shadow, can meet a big mesh; -1 when there is no big mesh or the area cannot be bounded.
 int first_heavy_row(const rt_transform* transforms, int32_t n_transforms, const FrameArgs& A) {
-    std::vector<WorldBox> boxes((size_t)n_transforms);
+    if (n_transforms > kMaxMeshes) return -1;
+    WorldBox boxes[kMaxMeshes];                 // no heap: this runs inside the entry point that allocates nothing
     double slo[3] = {1e300, 1e300, 1e300}, shi[3] = {-1e300, -1e300, -1e300};
     for (int32_t m = 0; m < n_transforms; m++) {
         boxes[(size_t)m] = world_box(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max);
@@ -378,6 +379,8 @@ int rt_ctx_create(int device, rt_ctx** out) {
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) { ctx->cfg.queue = ctx->d_queue; ctx->cfg.n_cus = cus > 0 ? cus : 256; }
+    // address of the library's file-scope staging array on this GPU (rt_render_frames_noalloc); `device` is current
+    if (e == hipSuccess) e = batch_scratch_init(device);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         rt_ctx_destroy(ctx);
@@ -721,6 +724,70 @@ int bad_strips(rt_ctx* ctx, int32_t stride, int32_t offset) {
 
 }  // namespace
 
+namespace {
+// rt_render_frames and rt_render_frames_noalloc.  The second form touches no allocator: the combined node
+// array must already be on the device (any earlier rendering call put it there), the per-frame constants go
+// from the context's page-locked staging slots into the library's file-scope device array, and the staging
+// slots, their events and the stream exist since rt_ctx_create.
+int render_frames_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms, int32_t n_frames,
+                       int32_t n_transforms, int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream, bool noalloc) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!camera || !light || !d_rgb) return fail(ctx, RT_ERR_INVALID, "camera, light and d_rgb are required");
+    if (n_frames < 1) return fail(ctx, RT_ERR_INVALID, "n_frames must be 1..RT_MAX_BATCH");
+    if (n_frames > RT_MAX_BATCH)
+        return fail(ctx, noalloc ? RT_ERR_CAPACITY : RT_ERR_INVALID,
+                    noalloc ? "n_frames exceeds RT_MAX_BATCH, the size of the library's static staging array" : "n_frames must be 1..RT_MAX_BATCH");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    if (frame_stride < (size_t)width * (size_t)height * 3) return fail(ctx, RT_ERR_INVALID, "frame_stride smaller than one image");
+    if (ctx->meshes.size() > (size_t)kMaxMeshes) return fail(ctx, RT_ERR_UNSUPPORTED, "more than RT_MAX_MESHES meshes: use rt_render_frame_instanced");
+    if (n_transforms != (int32_t)ctx->meshes.size() || (n_transforms > 0 && !transforms))
+        return fail(ctx, RT_ERR_INVALID, "one transform per uploaded mesh and frame is required");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (noalloc) {
+        if (ctx->scene_dirty)
+            return fail(ctx, RT_ERR_UNSUPPORTED, "the mesh list changed since the last rendering call: its node array is not on the device yet "
+                                                 "(render once through an allocating entry point, e.g. rt_render_frames, first)");
+        if ((size_t)n_frames * sizeof(FrameArgs) > batch_scratch_bytes()) return fail(ctx, RT_ERR_CAPACITY, "batch larger than the static staging array");
+    } else {
+        int cst = commit_scene(ctx);
+        if (cst != RT_OK) return cst;
+    }
+    const SceneArgs S = scene_args(ctx);
+
+    const int slot = (int)(ctx->batch_seq++ % (unsigned)kBatchSlots);
+    if (ctx->batch_used[slot]) RT_HIP(ctx, hipEventSynchronize(ctx->batch_done[slot]));
+    FrameArgs* h = ctx->h_batch + (size_t)slot * RT_MAX_BATCH;
+    FrameArgs* d = ctx->d_batch + (size_t)slot * RT_MAX_BATCH;
+    int first_row = -1;
+    bool bounded = true;
+    for (int32_t f = 0; f < n_frames; f++) {
+        const rt_transform* tf = transforms ? transforms + (size_t)f * (size_t)n_transforms : nullptr;
+        fill_frame(ctx, *camera, *light, tf, n_transforms, width, height, 0u, h[f]);
+        const int row = first_heavy_row(tf, n_transforms, h[f]);
+        if (row < 0) bounded = false;
+        else if (first_row < 0 || row < first_row) first_row = row;
+    }
+    if (!bounded || first_row < 0) first_row = 0;
+    const int chunk = ctx->batch_chunk > 0 ? ctx->batch_chunk : (4 * ((width + 7) / 8) + 63) / 64 * 64;
+    hipError_t le;
+    if (noalloc) {
+        if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
+        le = launch_batch_noalloc(ctx->device, h, n_frames, width, height, S, (uint8_t*)d_rgb, frame_stride, first_row, chunk, ctx->xcd_swizzle,
+                                  ctx->cfg.block, s);
+    } else {
+        RT_HIP(ctx, hipMemcpyAsync(d, h, (size_t)n_frames * sizeof(FrameArgs), hipMemcpyHostToDevice, s));
+        if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
+        le = launch_batch(d, n_frames, width, height, S, (uint8_t*)d_rgb, frame_stride, first_row, chunk, ctx->xcd_swizzle, ctx->cfg.block, s);
+    }
+    if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
+    if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
+    RT_HIP(ctx, hipEventRecord(ctx->batch_done[slot], s));
+    ctx->batch_used[slot] = true;
+    return RT_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
@@ -745,43 +812,12 @@ int rt_render_frame_strips(rt_ctx* ctx, const rt_camera* camera, const rt_light*
 
 int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms, int32_t n_frames,
                      int32_t n_transforms, int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream) {
-    if (!ctx) return RT_ERR_INVALID;
-    if (!camera || !light || !d_rgb) return fail(ctx, RT_ERR_INVALID, "camera, light and d_rgb are required");
-    if (n_frames < 1 || n_frames > RT_MAX_BATCH) return fail(ctx, RT_ERR_INVALID, "n_frames must be 1..RT_MAX_BATCH");
-    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
-    if (frame_stride < (size_t)width * (size_t)height * 3) return fail(ctx, RT_ERR_INVALID, "frame_stride smaller than one image");
-    if (ctx->meshes.size() > (size_t)kMaxMeshes) return fail(ctx, RT_ERR_UNSUPPORTED, "more than RT_MAX_MESHES meshes: use rt_render_frame_instanced");
-    if (n_transforms != (int32_t)ctx->meshes.size() || (n_transforms > 0 && !transforms))
-        return fail(ctx, RT_ERR_INVALID, "one transform per uploaded mesh and frame is required");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    int cst = commit_scene(ctx);
-    if (cst != RT_OK) return cst;
-    const SceneArgs S = scene_args(ctx);
+    return render_frames_impl(ctx, camera, light, transforms, n_frames, n_transforms, width, height, d_rgb, frame_stride, stream, false);
+}
 
-    const int slot = (int)(ctx->batch_seq++ % (unsigned)kBatchSlots);
-    if (ctx->batch_used[slot]) RT_HIP(ctx, hipEventSynchronize(ctx->batch_done[slot]));
-    FrameArgs* h = ctx->h_batch + (size_t)slot * RT_MAX_BATCH;
-    FrameArgs* d = ctx->d_batch + (size_t)slot * RT_MAX_BATCH;
-    int first_row = -1;
-    bool bounded = true;
-    for (int32_t f = 0; f < n_frames; f++) {
-        const rt_transform* tf = transforms ? transforms + (size_t)f * (size_t)n_transforms : nullptr;
-        fill_frame(ctx, *camera, *light, tf, n_transforms, width, height, 0u, h[f]);
-        const int row = first_heavy_row(tf, n_transforms, h[f]);
-        if (row < 0) bounded = false;
-        else if (first_row < 0 || row < first_row) first_row = row;
-    }
-    if (!bounded || first_row < 0) first_row = 0;
-    RT_HIP(ctx, hipMemcpyAsync(d, h, (size_t)n_frames * sizeof(FrameArgs), hipMemcpyHostToDevice, s));
-    if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    hipError_t le = launch_batch(d, n_frames, width, height, S, (uint8_t*)d_rgb, frame_stride, first_row,
-                                 ctx->batch_chunk > 0 ? ctx->batch_chunk : (4 * ((width + 7) / 8) + 63) / 64 * 64, ctx->xcd_swizzle, ctx->cfg.block, s);
-    if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
-    if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
-    RT_HIP(ctx, hipEventRecord(ctx->batch_done[slot], s));
-    ctx->batch_used[slot] = true;
-    return RT_OK;
+int rt_render_frames_noalloc(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms, int32_t n_frames,
+                             int32_t n_transforms, int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream) {
+    return render_frames_impl(ctx, camera, light, transforms, n_frames, n_transforms, width, height, d_rgb, frame_stride, stream, true);
 }
 
 }  // extern "C"

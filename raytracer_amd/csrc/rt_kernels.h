@@ -40,6 +40,15 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
 hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb, size_t frame_stride,
                         int first_row, int chunk, int swizzle, int block, hipStream_t stream);
 
+// The same launch with the per-frame constants staged in a file-scope device array of the library instead of a
+// buffer of the caller's context: h_frames (page-locked host memory, n_frames <= RT_MAX_BATCH records) is copied there
+// on `stream`, then the kernel is enqueued.  batch_scratch_init(device) must have succeeded once with `device`
+// current; neither call allocates.  All launches on one GPU share the array (order them on one stream).
+hipError_t batch_scratch_init(int device);
+size_t batch_scratch_bytes();
+hipError_t launch_batch_noalloc(int device, const FrameArgs* h_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb,
+                                size_t frame_stride, int first_row, int chunk, int swizzle, int block, hipStream_t stream);
+
 // Enqueues one sampled frame (X.spp camera rays per pixel, X.n_lights lights).  O.rgb is required,
 // O.hit_id optional (sample 0), the other planes are not written.  block: 64 or 256.
 hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneArgs& S, const OutputPlanes& O, int block, int split, hipStream_t stream);

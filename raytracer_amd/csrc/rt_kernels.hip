@@ -20,6 +20,8 @@
 // rt_render_frames uses render_batch (several frames per launch), see below.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "rt_kernels.h"
 #include "rt_pixel.h"
 #include "rt_instanced.h"
@@ -464,6 +466,56 @@ hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int 
     }
     if (block == 64) return launch_batch_t<64, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, stream);
     return launch_batch_t<256, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched frames for callers that cannot allocate (rt_render_frames_noalloc): the per-frame constants
+// that rt_render_frames stages in a device array of the context go through this file-scope array
+// instead.  Every GPU holds its own copy of the array at its own address until the process ends; its
+// address on a device is looked up once, with that device current (batch_scratch_init, called by
+// rt_ctx_create), and from then on host code uses that address only -- the array's name is not a
+// device address on the host side.  All launches on one GPU share the array: calls that overlap on
+// one GPU (different streams, or different contexts on the same device) race.
+// ------------------------------------------------------------------------------------------
+constexpr size_t kBatchScratchBytes = (size_t)RT_MAX_BATCH * sizeof(FrameArgs);
+static __device__ __align__(256) unsigned char scratch[kBatchScratchBytes];
+
+constexpr int kMaxScratchDevices = 64;
+static void* g_scratch_ptr[kMaxScratchDevices] = {};
+static std::mutex g_scratch_lock;
+
+hipError_t batch_scratch_init(int device) {
+    if (device < 0 || device >= kMaxScratchDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> guard(g_scratch_lock);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    int current = -1;
+    hipError_t e = hipGetDevice(&current);
+    if (e != hipSuccess) return e;
+    if (current != device) return hipErrorInvalidDevice;       // the address differs from GPU to GPU
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
+
+size_t batch_scratch_bytes() { return kBatchScratchBytes; }
+
+hipError_t launch_batch_noalloc(int device, const FrameArgs* h_frames, int n_frames, int width, int height, const SceneArgs& S, uint8_t* rgb,
+                                size_t frame_stride, int first_row, int chunk, int swizzle, int block, hipStream_t stream) {
+    if (device < 0 || device >= kMaxScratchDevices || !h_frames) return hipErrorInvalidValue;
+    if (n_frames < 1 || (size_t)n_frames * sizeof(FrameArgs) > kBatchScratchBytes) return hipErrorInvalidValue;
+    void* ptr;
+    {
+        std::lock_guard<std::mutex> guard(g_scratch_lock);
+        ptr = g_scratch_ptr[device];
+    }
+    if (!ptr) return hipErrorNotInitialized;
+    // every byte the kernel reads is written here first: nothing of an earlier call is left to clear
+    hipError_t e = hipMemcpyAsync(ptr, h_frames, (size_t)n_frames * sizeof(FrameArgs), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    return launch_batch(static_cast<const FrameArgs*>(ptr), n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, block, stream);
 }
 
 // ------------------------------------------------------------------------------------------
