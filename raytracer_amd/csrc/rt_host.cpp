@@ -85,6 +85,7 @@ struct rt_ctx {
     int budget = 48;               // two-pass variant: node visits per pixel before it is deferred
     int resident_budget = (int)kResidentBudget;   // bytes of small meshes staged in LDS by the lean kernels
     int xcd_swizzle = 1;           // rt_render_frames: give each XCD runs of 8 neighbouring tiles
+    int batch_rows = 1;            // rt_render_frames: 1 = each frame scans its tile rows from its own first heavy row, 0 = from the batch's
     int batch_chunk = 0;           // rt_render_frames: consecutive tiles of one frame before the next frame's; 0 = four tile rows
     int coop = 1;                  // cooperative rendering of the big meshes' screen area (variant 3)
     // rt_render_frames: per-frame constants travel through a ring of staging slots (pinned host
@@ -765,10 +766,12 @@ int render_frames_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* lig
         const rt_transform* tf = transforms ? transforms + (size_t)f * (size_t)n_transforms : nullptr;
         fill_frame(ctx, *camera, *light, tf, n_transforms, width, height, 0u, h[f]);
         const int row = first_heavy_row(tf, n_transforms, h[f]);
+        h[f].first_tile_row = row > 0 && row < (height + 7) / 8 ? row : 0;
         if (row < 0) bounded = false;
         else if (first_row < 0 || row < first_row) first_row = row;
     }
     if (!bounded || first_row < 0) first_row = 0;
+    if (ctx->batch_rows) first_row = -1;               // every frame of the batch starts at its own heavy rows
     const int chunk = ctx->batch_chunk > 0 ? ctx->batch_chunk : (4 * ((width + 7) / 8) + 63) / 64 * 64;
     hipError_t le;
     if (noalloc) {
@@ -1144,6 +1147,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
         if (st != RT_OK) return st;
         ctx->frames_in_flight = value; ctx->ring_seq = 0; return RT_OK;
     }
+    if (!strcmp(name, "batch_rows")) { ctx->batch_rows = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "batch_chunk")) {
         if (value < 0 || value > (1 << 20)) return fail(ctx, RT_ERR_INVALID, "batch_chunk out of range");
         ctx->batch_chunk = value; return RT_OK;
@@ -1170,6 +1174,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "frames_in_flight")) { *value = ctx->frames_in_flight; return RT_OK; }
     if (!strcmp(name, "keep_hierarchy")) { *value = ctx->keep_hierarchy; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
+    if (!strcmp(name, "batch_rows")) { *value = ctx->batch_rows; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }
     if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }
     if (!strcmp(name, "default_variant")) { *value = kDefaultVariant; return RT_OK; }

@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(BLOCK) render_batch(const FrameArgs* __restric
     if (slot >= tiles_x * tiles_y) return;
     int row = slot / tiles_x;
     const int col = slot - row * tiles_x;
-    row += first_row;
+    row += first_row >= 0 ? first_row : A.first_tile_row;      // one starting row for the batch, or each frame's own
     if (row >= tiles_y) row -= tiles_y;
     const int lane = threadIdx.x & 63;
     const int px = col * 8 + (lane & 7), py = row * 8 + (lane >> 3);
@@ -458,7 +458,7 @@ hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int 
                         int first_row, int chunk, int swizzle, int block, hipStream_t stream) {
     if (n_frames <= 0 || width <= 0 || height <= 0 || !d_frames || !rgb) return hipErrorInvalidValue;
     const int tiles_y = (height + 7) / 8;
-    if (first_row < 0 || first_row >= tiles_y) first_row = 0;
+    if (first_row >= tiles_y) first_row = 0;                   // < 0: every frame starts at its own FrameArgs::first_tile_row
     if (chunk < 1) chunk = 1;
     if (S.stack_entries <= 16) {
         if (block == 64) return launch_batch_t<64, 16>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, stream);

@@ -94,7 +94,8 @@ struct FrameArgs {
     // strip_offset (one rank's share of a frame split over several GPUs): row py of the launch is row
     // frame_row(py) of the frame.  A whole frame is full_height = height, stride 1, offset 0.
     int32_t width, height;
-    int32_t full_height, strip_stride, strip_offset, pad_rows;
+    int32_t full_height, strip_stride, strip_offset;
+    int32_t first_tile_row;      // batched frames: tile row this frame's waves start scanning at (its heavy tiles first), 0 otherwise
     int32_t n_mesh;
     uint32_t flags;
     float cam_pos[3];

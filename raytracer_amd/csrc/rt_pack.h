@@ -365,7 +365,7 @@ inline void fill_camera(const rt_camera& cam, const rt_light& light, int32_t wid
     const F3 right = unit(cross(fwd, f3(cam.up)));
     const F3 up = cross(right, fwd);
     A.width = width; A.height = height;
-    A.full_height = height; A.strip_stride = 1; A.strip_offset = 0; A.pad_rows = 0;
+    A.full_height = height; A.strip_stride = 1; A.strip_offset = 0; A.first_tile_row = 0;
     A.cam_pos[0] = cam.position.x; A.cam_pos[1] = cam.position.y; A.cam_pos[2] = cam.position.z;
     A.cam_right[0] = right.x; A.cam_right[1] = right.y; A.cam_right[2] = right.z;
     A.cam_up[0] = up.x; A.cam_up[1] = up.y; A.cam_up[2] = up.z;
