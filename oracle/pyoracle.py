@@ -125,6 +125,9 @@ def lib():
         L.orc_build_bvh.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         L.orc_load_obj.restype = C.c_int32
         L.orc_load_obj.argtypes = [C.c_char_p, C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 3
+        L.orc_render_frame_ids.restype = None
+        L.orc_render_frame_ids.argtypes = [C.POINTER(Mesh), C.c_int32, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [
+            C.POINTER(Counters), C.c_int32]
         L.orc_render_frame.restype = None
         L.orc_render_frame.argtypes = [C.POINTER(Mesh), C.c_int32, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int32]
@@ -301,6 +304,21 @@ def render_frame(meshes: Sequence[HostMesh], transforms: Sequence[Transform], ca
                            _ptr(hid) if debug else None, _ptr(ht) if debug else None, _ptr(sh) if debug else None,
                            C.byref(cnt), threads)
     return Frame(rgb, hid, ht, sh, cnt.as_dict())
+
+
+def render_frame_ids(meshes: Sequence[HostMesh], transforms: Sequence[Transform], cam: Camera, light: Light,
+                     width: int, height: int, threads: int = 0):
+    """render_frame for mesh lists of any length: returns (Frame with hit_id = None, hit_mesh [h,w] i32, hit_tri [h,w] i32)."""
+    arr = (Mesh * len(meshes))(*[m.as_struct(tf) for m, tf in zip(meshes, transforms)])
+    rgb = np.zeros((height, width, 3), np.uint8)
+    hm = np.zeros((height, width), np.int32)
+    htri = np.zeros((height, width), np.int32)
+    ht = np.zeros((height, width), np.float32)
+    sh = np.zeros((height, width), np.uint8)
+    cnt = Counters()
+    lib().orc_render_frame_ids(arr, len(meshes), C.byref(cam), C.byref(light), width, height, _ptr(rgb), _ptr(hm), _ptr(htri), _ptr(ht),
+                               _ptr(sh), C.byref(cnt), threads)
+    return Frame(rgb, None, ht, sh, cnt.as_dict()), hm, htri
 
 
 def render_frame_sampled(meshes: Sequence[HostMesh], transforms: Sequence[Transform], cam: Camera, lights: Sequence[Light],

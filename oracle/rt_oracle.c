@@ -391,9 +391,9 @@ void orc_upscale_frame(const uint8_t* frame, int width, int height, int scaled_w
 }
 
 /* ------------------------------------------------------------------ the frame loop (scene.c:52-160) */
-void orc_render_frame(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* light,
-                      int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_id, float* hit_t,
-                      uint8_t* shadow, OCounters* counters, int32_t threads) {
+static void render_frame_planes(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* light,
+                                int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_id, float* hit_t,
+                                uint8_t* shadow, OCounters* counters, int32_t threads, int32_t* hit_mesh_out, int32_t* hit_tri_out) {
     float aspect = (float)width / height;                       /* scene.c:53 */
     uint64_t c_prim = 0, c_shad = 0, c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
 #ifdef _OPENMP
@@ -455,6 +455,8 @@ void orc_render_frame(const OMesh* meshes, int32_t mesh_count, const OCamera* ca
                 out[0] = out[1] = out[2] = 50;                   /* scene.c:156 */
             }
             if (hit_id) hit_id[px] = hit ? ((hit_mesh << 24) | hit_tri) : -1;
+            if (hit_mesh_out) hit_mesh_out[px] = hit ? hit_mesh : -1;
+            if (hit_tri_out) hit_tri_out[px] = hit ? hit_tri : -1;
             if (hit_t) hit_t[px] = closest;
             if (shadow) shadow[px] = sh;
             c_slab += w.slabs; c_tri += w.tris;
@@ -465,6 +467,18 @@ void orc_render_frame(const OMesh* meshes, int32_t mesh_count, const OCamera* ca
         counters->slab_tests = c_slab; counters->tri_tests = c_tri;
         counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
     }
+}
+
+void orc_render_frame(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* light,
+                      int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_id, float* hit_t,
+                      uint8_t* shadow, OCounters* counters, int32_t threads) {
+    render_frame_planes(meshes, mesh_count, cam, light, width, height, rgb, hit_id, hit_t, shadow, counters, threads, NULL, NULL);
+}
+
+void orc_render_frame_ids(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* light,
+                          int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_mesh, int32_t* hit_tri, float* hit_t,
+                          uint8_t* shadow, OCounters* counters, int32_t threads) {
+    render_frame_planes(meshes, mesh_count, cam, light, width, height, rgb, NULL, hit_t, shadow, counters, threads, hit_mesh, hit_tri);
 }
 
 /* ------------------------------------------------------------------ sampled frames (beyond the reference)

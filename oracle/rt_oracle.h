@@ -104,6 +104,13 @@ void   orc_render_frame(const OMesh* meshes, int32_t mesh_count, const OCamera* 
                         uint8_t* rgb, int32_t* hit_id, float* hit_t, uint8_t* shadow,
                         OCounters* counters, int32_t threads);
 
+/* The same frame with the hit reported as two planes, list index of the mesh and triangle index (-1 = miss), for
+ * mesh lists too long for the packed id. */
+void   orc_render_frame_ids(const OMesh* meshes, int32_t mesh_count, const OCamera* cam,
+                            const OLight* light, int32_t width, int32_t height,
+                            uint8_t* rgb, int32_t* hit_mesh, int32_t* hit_tri, float* hit_t, uint8_t* shadow,
+                            OCounters* counters, int32_t threads);
+
 /* Animation of the reference's driver (raytracer.c:41-53): placements of the drone
  * (mesh 0) and the treasure (mesh 1) at a frame; the ground keeps the identity. */
 void   orc_animation_transforms(int32_t frame, OTransform out[3]);

@@ -79,6 +79,9 @@ BVHNode* create_bvh_node(Triangle* triangles, int start, int count);
 BVH create_bvh(Triangle* triangles, size_t count);
 void destroy_bvh_node(BVHNode* node);
 void destroy_bvh(BVH* bvh);
+/* One ray against one mesh on the HOST (the reference's CPU traversal, for programs that call it directly;
+ * render_scene does not use it). */
+bool intersect_bvh(BVHNode* node, Ray ray, const Triangle* triangles, float* t_out, float* u_out, float* v_out, int* tri_idx);
 
 /* render/camera.h:15, render/light.h:12 */
 Camera create_camera(Vec3 position, Vec3 look_at, Vec3 up, float fov);
@@ -86,7 +89,7 @@ DirectionalLight create_directional_light(Vec3 direction, Vec3 color);
 
 /* Value-type helpers of math/vec3.h:10-18, math/mat4.h:11-20, math/ray.h:18-21, geometry/aabb.h:15-18,
  * render/camera.h:16 and utils/image.h:7-9, with the reference's float results.  Host utilities only:
- * the frame path does not use them (intersect_bvh, the reference's CPU traversal, is not provided). */
+ * the frame path does not use them. */
 Vec3 vec3_add(Vec3 a, Vec3 b);
 Vec3 vec3_sub(Vec3 a, Vec3 b);
 Vec3 vec3_mul(Vec3 a, float t);

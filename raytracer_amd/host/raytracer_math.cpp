@@ -3,7 +3,7 @@
 // written against them keep linking.  They are built from the same float building blocks the
 // device code uses (csrc/rt_exact.h, csrc/rt_bicubic.h; FMA contraction off), so their results are
 // the ones the GPU path is tested against.  None of them is on the frame path: render_scene() does
-// not call them, and there is deliberately no host-side BVH traversal here.
+// not call them; intersect_bvh is a one-ray utility for programs written against accel/bvh.h.
 #include <math.h>
 #include <string.h>
 
@@ -19,9 +19,59 @@ inline Mat4 out(const rt::M4& m) { Mat4 r; memcpy(r.m, m.m, sizeof r.m); return 
 inline rt::M4 rotation_of(Transform tf) {                                             // ray.c:7-9
     return rt::m4_mul(rt::m4_rotation(2, tf.rotation.z), rt::m4_mul(rt::m4_rotation(1, tf.rotation.y), rt::m4_rotation(0, tf.rotation.x)));
 }
+
+// Result of the reference's traversal below one node (accel/bvh.c:80-129).
+struct Found {
+    bool hit;
+    float t, u, v;
+    int idx;
+};
+
+// A leaf keeps the closest accepted triangle below `bound` (strict, so the lowest index wins equal distances);
+// an inner node asks both children with a fresh bound of 1e30f and keeps the left answer only when it is
+// strictly closer than the right one.  The caller's bound therefore matters in a root that is a leaf only.
+Found walk(const BVHNode* node, rt::F3 o, rt::F3 d, rt::F3 inv, const Triangle* tris, float bound) {
+    Found f = {false, 0.0f, 0.0f, 0.0f, -1};
+    const float lo[3] = {node->bounds.min.x, node->bounds.min.y, node->bounds.min.z};
+    const float hi[3] = {node->bounds.max.x, node->bounds.max.y, node->bounds.max.z};
+    if (!rt::slab(o, inv, lo, hi)) return f;
+    if (!node->left && !node->right) {
+        for (int i = 0; i < node->triangle_count; i++) {
+            const Triangle& T = tris[node->start_idx + i];
+            const rt::F3 a = in(T.v0);
+            float t, u, v;
+            if (rt::moller_trumbore(o, d, a, rt::sub(in(T.v1), a), rt::sub(in(T.v2), a), t, u, v) && t < bound) {
+                bound = t;
+                f.hit = true; f.t = t; f.u = u; f.v = v; f.idx = node->start_idx + i;
+            }
+        }
+        return f;
+    }
+    Found l = f, r = f;
+    if (node->left) l = walk(node->left, o, d, inv, tris, 1e30f);
+    if (node->right) r = walk(node->right, o, d, inv, tris, 1e30f);
+    if (l.hit && (!r.hit || l.t < r.t)) return l;
+    return r;
+}
 }  // namespace
 
 extern "C" {
+
+// ---- accel/bvh.h:27-28 ----
+// One ray against one mesh's tree on the host, as accel/bvh.c:80-129 does it: every box whose ancestors' boxes
+// the ray passes is visited, the reciprocal direction is the one ray_aabb_intersect derives per call.  Outputs
+// are written on a hit only.
+bool intersect_bvh(BVHNode* node, Ray ray, const Triangle* triangles, float* t_out, float* u_out, float* v_out, int* tri_idx) {
+    if (!node || !t_out) return false;
+    const rt::F3 d = in(ray.direction);
+    const Found f = walk(node, in(ray.origin), d, rt::recip(d), triangles, *t_out);
+    if (!f.hit) return false;
+    *t_out = f.t;
+    if (u_out) *u_out = f.u;
+    if (v_out) *v_out = f.v;
+    if (tri_idx) *tri_idx = f.idx;
+    return true;
+}
 
 // ---- math/vec3.h:10-18 ----
 Vec3 vec3_add(Vec3 a, Vec3 b) { return out(rt::add(in(a), in(b))); }

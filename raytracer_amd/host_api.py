@@ -85,7 +85,7 @@ assert C.sizeof(Triangle) == 96 and C.sizeof(BVHNode) == 48 and C.sizeof(Camera)
 EXPORTS = [
     "create_scene", "add_mesh_to_scene", "set_scene_camera", "set_scene_light", "next_frame", "render_scene",
     "save_scene", "destroy_scene", "create_mesh", "set_mesh_position", "set_mesh_rotation", "destroy_mesh",
-    "sample_mesh_texture", "create_bvh_node", "create_bvh", "destroy_bvh_node", "destroy_bvh", "create_camera",
+    "sample_mesh_texture", "create_bvh_node", "create_bvh", "destroy_bvh_node", "destroy_bvh", "intersect_bvh", "create_camera",
     "create_directional_light", "rt_host_set_device", "rt_host_last_status", "rt_host_render_debug",
     "rt_host_demo_animation", "rt_host_write_ppm", "rt_host_scaled_size", "rt_host_upscale_frame",
     "rt_host_set_obj_mode", "rt_host_animation_has_webp", "rt_host_animation_open", "rt_host_animation_add",
@@ -134,6 +134,8 @@ def lib():
         L.destroy_bvh_node.argtypes = [C.POINTER(BVHNode)]
         L.destroy_bvh.restype = None
         L.destroy_bvh.argtypes = [C.POINTER(BVH)]
+        L.intersect_bvh.restype = C.c_bool
+        L.intersect_bvh.argtypes = [C.POINTER(BVHNode), Ray, C.POINTER(Triangle)] + [C.POINTER(C.c_float)] * 3 + [C.POINTER(C.c_int)]
         L.create_camera.restype = Camera
         L.create_camera.argtypes = [Vec3, Vec3, Vec3, C.c_float]
         L.create_directional_light.restype = DirectionalLight

@@ -65,8 +65,8 @@ def test_host_library_exports_the_reference_api(host):
     """Names of scene.h:29-36, geometry/mesh.h:22-26, accel/bvh.h:23-28, render/camera.h:15, render/light.h:12."""
     for n in ("create_scene", "add_mesh_to_scene", "set_scene_camera", "set_scene_light", "next_frame", "render_scene",
               "save_scene", "destroy_scene", "create_mesh", "set_mesh_position", "set_mesh_rotation", "destroy_mesh",
-              "sample_mesh_texture", "create_bvh_node", "create_bvh", "destroy_bvh_node", "destroy_bvh", "create_camera",
-              "create_directional_light"):
+              "sample_mesh_texture", "create_bvh_node", "create_bvh", "destroy_bvh_node", "destroy_bvh", "intersect_bvh",
+              "create_camera", "create_directional_light"):
         assert hasattr(host.lib(), n), n
 
 
@@ -417,6 +417,46 @@ def test_value_type_helpers_equal_reference_vectors(host, golden_kat, golden_fra
                     for k in range(g["bic_x"].shape[0])], np.uint32)
     assert np.array_equal(got, g["bic_out"])
     assert H.get_pixel_rgb(frame.ctypes.data, -5, 999, 240, 135) == (int(frame[134, 0, 0]) << 16 | int(frame[134, 0, 1]) << 8 | int(frame[134, 0, 2]))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_intersect_bvh_equals_reference_vectors(host, golden_kat, name):
+    """intersect_bvh (accel/bvh.h:27-28, bvh.c:80-129) of the host library on the tree create_mesh builds: hit flag,
+    t, u, v and triangle index of 2048 rays per mesh as the compiled reference returned them."""
+    H = host.lib()
+    g = golden_kat
+    m = H.create_mesh(os.path.join(host.ASSETS, name + ".obj").encode(), os.path.join(host.ASSETS, name + ".webp").encode())
+    try:
+        n = g[f"bvh_{name}_hit"].shape[0]
+        hit, tuv, idx = np.zeros(n, np.int32), np.zeros((n, 3), np.float32), np.full(n, -1, np.int32)
+        v3 = lambda a: host.Vec3(float(a[0]), float(a[1]), float(a[2]))          # noqa: E731
+        for k in range(n):
+            t, u, v, i = C.c_float(1e30), C.c_float(-7), C.c_float(-7), C.c_int(-1)
+            hit[k] = H.intersect_bvh(m.bvh.root, host.Ray(v3(g[f"bvh_{name}_o"][k]), v3(g[f"bvh_{name}_d"][k])), m.triangles,
+                                     C.byref(t), C.byref(u), C.byref(v), C.byref(i))
+            if hit[k]:
+                tuv[k] = (t.value, u.value, v.value)
+                idx[k] = i.value
+            else:
+                assert (t.value, u.value, v.value, i.value) == (np.float32(1e30), -7, -7, -1)      # outputs untouched on a miss
+        assert np.array_equal(hit, g[f"bvh_{name}_hit"]) and np.array_equal(idx, g[f"bvh_{name}_idx"])
+        assert np.array_equal(bits(tuv), bits(g[f"bvh_{name}_tuv"]))
+        # a root that is a leaf honours the caller's bound (bvh.c:85); an inner root ignores it (bvh.c:106)
+        k = int(np.flatnonzero(hit)[0])
+        ray = host.Ray(v3(g[f"bvh_{name}_o"][k]), v3(g[f"bvh_{name}_d"][k]))
+        t = C.c_float(tuv[k, 0] * 0.5)
+        u, v, i = C.c_float(0), C.c_float(0), C.c_int(-1)
+        assert H.intersect_bvh(m.bvh.root, ray, m.triangles, C.byref(t), C.byref(u), C.byref(v), C.byref(i)) and t.value == tuv[k, 0]
+        tri = (host.Triangle * 1)(m.triangles[int(idx[k])])
+        leaf = H.create_bvh(tri, 1)
+        t = C.c_float(tuv[k, 0] * 0.5)
+        assert not H.intersect_bvh(leaf.root, ray, tri, C.byref(t), C.byref(u), C.byref(v), C.byref(i))
+        t = C.c_float(1e30)
+        assert H.intersect_bvh(leaf.root, ray, tri, C.byref(t), C.byref(u), C.byref(v), C.byref(i)) and i.value == 0
+        assert np.float32(t.value) == tuv[k, 0]
+        H.destroy_bvh(C.byref(leaf))
+    finally:
+        H.destroy_mesh(C.byref(m))
 
 
 def test_vec3_mat4_aabb_helpers(host):

@@ -216,3 +216,104 @@ def test_c_abi_walk_through_from_a_compiled_program():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert json.loads(r.stdout.strip().splitlines()[-1]) == {"errors": 0}
+
+
+# ------------------------------------------------------------------ tolerant OBJ reader, end to end on the GPU
+def _terrain_obj(n=12):
+    """A height field written the ways the reference's reader cannot take (mesh.c:41-76 reads triangles with
+    v/vt/vn corners only): quads and five-corner faces, corners without texture coordinates (v//vn), and faces
+    that count from the end of the lists.  Every number is a multiple of 1/64, so any parser reads the same
+    float.  Returns (text, the triangles a fan over each face gives, in file order, [k, 24] float32)."""
+    rng = np.random.default_rng(11)
+    q = lambda a: np.round(np.asarray(a, np.float64) * 64) / 64          # noqa: E731
+    xs = q(np.linspace(-2.0, 2.0, n + 1))
+    hgt = q(0.3 + 0.25 * rng.random((n + 1, n + 1)))
+    v = np.array([[xs[i], hgt[j, i], xs[j]] for j in range(n + 1) for i in range(n + 1)])
+    vt = q(np.array([[i / n, j / n] for j in range(n + 1) for i in range(n + 1)]))
+    vn = q(np.array([[0.0, 1.0, 0.0], [0.25, 0.9375, 0.0], [0.0, 0.9375, -0.25], [-0.125, 0.96875, 0.125]]))
+    lines = ["# terrain"] + ["v %r %r %r" % tuple(map(float, p)) for p in v]
+    lines += ["vt %r %r" % tuple(map(float, p)) for p in vt] + ["vn %r %r %r" % tuple(map(float, p)) for p in vn]
+    nv, nt, nn = len(v), len(vt), len(vn)
+    tris = []
+
+    def corner(iv, it, inn):
+        return v[iv], (vt[it] if it is not None else np.zeros(2)), vn[inn]
+
+    def emit(corners, style):
+        toks = []
+        for iv, it, inn in corners:
+            if style == "neg":
+                toks.append("%d/%d/%d" % (iv - nv, it - nt, inn - nn))
+            elif style == "novt":
+                toks.append("%d//%d" % (iv + 1, inn + 1))
+            else:
+                toks.append("%d/%d/%d" % (iv + 1, it + 1, inn + 1))
+        lines.append("f " + " ".join(toks))
+        cs = [corner(iv, None if style == "novt" else it, inn) for iv, it, inn in corners]
+        for k in range(1, len(cs) - 1):                                     # the fan: corners 0, k, k+1
+            a, b, c = cs[0], cs[k], cs[k + 1]
+            tris.append(np.concatenate([a[0], b[0], c[0], a[1], b[1], c[1], a[2], b[2], c[2]]))
+
+    idx = lambda i, j: j * (n + 1) + i                                       # noqa: E731
+    for j in range(n):
+        for i in range(n):
+            k = (i + j) % 4
+            quad = [(idx(i, j), idx(i, j), k), (idx(i, j + 1), idx(i, j + 1), k), (idx(i + 1, j + 1), idx(i + 1, j + 1), k),
+                    (idx(i + 1, j), idx(i + 1, j), k)]
+            style = ("plain", "neg", "novt")[(i * 7 + j * 3) % 3]
+            if i + 2 <= n and (i + j) % 5 == 0 and i % 2 == 0:               # a five-corner face over this cell and half of the next
+                emit(quad[:3] + [(idx(i + 2, j + 1), idx(i + 2, j + 1), k), quad[3]], style)
+            else:
+                emit(quad, style)
+    return "\n".join(lines) + "\n", np.array(tris, np.float32)
+
+
+def test_tolerant_obj_through_create_mesh_renders_like_the_same_triangles_uploaded(capi, po, tmp_path):
+    """create_mesh in tolerant mode on quads, five-corner faces, v//vn corners and negative indices -> render_scene on
+    the GPU, against (a) the same triangles, fanned out here, uploaded as a soup through the C ABI and (b) the oracle's
+    reference loop on its own build of that soup.  The reference's reader has no output for such a file (its sscanf
+    pattern skips these faces), so the reader's semantics are pinned by this fan-out, not by the reference."""
+    import ctypes as C
+    import os
+    from raytracer_amd import host_api as H
+    text, soup = _terrain_obj()
+    obj = tmp_path / "terrain.obj"
+    obj.write_text(text)
+    L = H.lib()
+    w, h = 320, 180
+    L.rt_host_set_obj_mode(1)
+    try:
+        m = L.create_mesh(str(obj).encode(), os.path.join(H.ASSETS, "ground.webp").encode())
+    finally:
+        L.rt_host_set_obj_mode(0)
+    assert m.bvh.root and int(m.triangle_count) == soup.shape[0]
+    parsed = H.mesh_triangles(m)
+    key = lambda a: sorted(r.tobytes() for r in a)                           # noqa: E731
+    assert key(parsed) == key(soup), "the reader's triangles are not the fan over each face"
+    rgba = H.mesh_texture(m)
+    scene = L.create_scene(w, h, 1000, 1, 1.0)
+    L.set_scene_camera(C.byref(scene), H.Vec3(-3, 3, -3), H.Vec3(0, 0, 0), H.Vec3(0, 1, 0), 60.0)
+    L.set_scene_light(C.byref(scene), H.Vec3(1, 1, -1), H.Vec3(1.4, 1.4, 1.4))
+    L.add_mesh_to_scene(C.byref(scene), m)
+    L.set_mesh_rotation(C.byref(scene.meshes[0]), H.Vec3(0.0, 0.5, 0.0))
+    L.render_scene(C.byref(scene))
+    assert L.rt_host_last_status(C.byref(scene)) == 0
+    got_rgb = H.frame_array(scene, 0)
+    hid, ht, sh = np.zeros((h, w), np.int32), np.zeros((h, w), np.float32), np.zeros((h, w), np.uint8)
+    assert L.rt_host_render_debug(C.byref(scene), hid.ctypes.data, ht.ctypes.data, sh.ctypes.data) == 0
+    L.destroy_mesh(C.byref(m))
+    L.destroy_scene(C.byref(scene))
+
+    tf = capi.Transform(capi.Vec3(0, 0, 0), capi.Vec3(0.0, 0.5, 0.0))
+    cam, light = camera_light(capi, po)
+    with capi.Context(0) as c:
+        c.upload_soup(soup, rgba)
+        rgb2, hid2, ht2, sh2 = c.render_host(cam, light, [tf], w, h)
+    assert np.array_equal(got_rgb, rgb2) and np.array_equal(hid, hid2) and np.array_equal(sh, sh2)
+    assert np.array_equal(ht.view(np.uint32), ht2.view(np.uint32))
+    t_post, nodes = po.build_bvh(soup)
+    want = po.render_frame([po.HostMesh(t_post, nodes, rgba)], [po.Transform(po.vec3(0, 0, 0), po.vec3(0.0, 0.5, 0.0))],
+                           po.default_camera(), po.default_light(), w, h)
+    assert np.array_equal(got_rgb, want.rgb) and np.array_equal(hid, want.hit_id) and np.array_equal(sh, want.shadow)
+    assert np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32))
+    assert int((hid >= 0).sum()) > w * h // 10 and len(np.unique(hid)) > 100

@@ -25,10 +25,7 @@ def grid_scene(po, n_side, seed, frame=10, spacing=1.1):
 
 
 def oracle_planes(po, meshes, ids, tfs, cam, light, w, h):
-    fr = po.render_frame([meshes[i] for i in ids], tfs, cam, light, w, h)
-    assert len(ids) < 128                                   # the oracle packs (list index << 24) | triangle into one int32
-    inst = np.where(fr.hit_id >= 0, fr.hit_id >> 24, -1)
-    tri = np.where(fr.hit_id >= 0, fr.hit_id & 0xFFFFFF, -1)
+    fr, inst, tri = po.render_frame_ids([meshes[i] for i in ids], tfs, cam, light, w, h)     # list index and triangle as two planes
     return fr, inst, tri
 
 
@@ -112,20 +109,15 @@ def test_single_leaf_meshes_and_empty_meshes_as_instances(po, meshes):
 
 def test_thousands_of_instances_against_the_reference_loop(po, meshes, em_default):
     """3 138 list entries (about 9.9 million placed triangles) at 64x36: the reference's loop over all of them per ray
-    is slow but still feasible at this size.  Its packed id (mesh << 24 | triangle) wraps for mesh >= 128, so the
-    instance is compared modulo 256."""
+    is slow but still feasible at this size.  The oracle reports list index and triangle as two planes here (its packed
+    id, mesh << 24 | triangle, wraps for long lists)."""
     ids, tfs = grid_scene(po, 56, seed=3, spacing=1.05)
     assert len(ids) == 56 * 56 + 2
     w, h = 64, 36
-    fr = po.render_frame([meshes[i] for i in ids], tfs, po.default_camera(), po.default_light(), w, h)
+    fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), w, h)
     got = em_default.render_instanced(po.default_camera(), po.default_light(), ids, tfs, w, h)
-    assert np.array_equal(got["rgb"], fr.rgb)
-    assert np.array_equal(bits(got["hit_t"]), bits(fr.hit_t))
-    assert np.array_equal(got["shadow"], fr.shadow)
-    hit = fr.hit_t < 1e30
-    assert np.array_equal(got["hit_inst"] >= 0, hit)
-    assert np.array_equal(got["hit_tri"][hit], fr.hit_id[hit] & 0xFFFFFF)
-    assert np.array_equal(got["hit_inst"][hit] & 0xFF, (fr.hit_id[hit] >> 24) & 0xFF)
+    check(got, fr, inst, tri)
+    assert inst.max() > 255
     assert got["tlas_depth"] <= 14 and len(np.unique(got["hit_inst"])) > 50
 
 
@@ -289,13 +281,10 @@ def test_gpu_large_instance_list_against_cpu_pipeline(gscene, po, meshes, em_def
     assert len(np.unique(got["hit_inst"])) > 200
     # and a small frame of the same scene straight against the reference's loop over all 3 138 meshes
     w, h = 96, 54
-    fr = po.render_frame([meshes[i] for i in ids], tfs, po.default_camera(), po.default_light(), w, h)
+    fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), w, h)
     got = gpu_render(gscene, po, ids, tfs, w, h)
-    assert np.array_equal(got["rgb"], fr.rgb) and np.array_equal(got["shadow"], fr.shadow)
-    assert np.array_equal(bits(got["hit_t"]), bits(fr.hit_t))
-    hit = fr.hit_t < 1e30
-    assert np.array_equal(got["hit_tri"][hit], fr.hit_id[hit] & 0xFFFFFF)
-    assert np.array_equal(got["hit_inst"][hit] & 0xFF, (fr.hit_id[hit] >> 24) & 0xFF)
+    check(got, fr, inst, tri)                             # full list indices (up to 3 137), not their low bits
+    assert inst.max() > 255
 
 
 @pytest.mark.gpu
