@@ -28,12 +28,31 @@ namespace {
 // ------------------------------------------------------------------ device side-table
 // The reference's Scene has no room for a device handle and is passed around by value, so the
 // GPU context lives in a table keyed by the scene's frame-pointer array (unique while alive).
+// `stamp` tells two trees apart that were built one after the other at the same address: malloc readily hands a
+// freed root's address to the next create_bvh, and a rebuilt tree means changed triangles.
 struct MeshKey {
-    const void* tris; const void* tex; const void* root; size_t n; int tw, th;
+    const void* tris; const void* tex; const void* root; size_t n; int tw, th; uint64_t stamp;
     bool operator==(const MeshKey& o) const {
-        return tris == o.tris && tex == o.tex && root == o.root && n == o.n && tw == o.tw && th == o.th;
+        return tris == o.tris && tex == o.tex && root == o.root && n == o.n && tw == o.tw && th == o.th && stamp == o.stamp;
     }
 };
+std::mutex g_stamp_lock;
+std::map<const void*, uint64_t> g_root_stamp;     // root of every tree built by this library -> its build number
+uint64_t g_builds = 0;
+void stamp_root(const void* root) {
+    if (!root) return;
+    std::lock_guard<std::mutex> g(g_stamp_lock);
+    g_root_stamp[root] = ++g_builds;
+}
+void forget_root(const void* root) {
+    std::lock_guard<std::mutex> g(g_stamp_lock);
+    g_root_stamp.erase(root);
+}
+uint64_t stamp_of(const void* root) {
+    std::lock_guard<std::mutex> g(g_stamp_lock);
+    auto it = g_root_stamp.find(root);
+    return it == g_root_stamp.end() ? 0 : it->second;       // 0: a tree the caller linked together itself
+}
 struct SceneState {
     rt_ctx* ctx = nullptr;
     int in_flight = 1;                    // the context's "frames_in_flight" as last set
@@ -71,7 +90,7 @@ int sync_scene(Scene* scene, SceneState& st, std::vector<int32_t>& geometry_of) 
     geometry_of.assign(scene->mesh_count, -1);
     for (size_t i = 0; i < scene->mesh_count; i++) {
         const Mesh& m = scene->meshes[i];
-        const MeshKey k{m.triangles, m.texture_data, m.bvh.root, m.triangle_count, m.texture_width, m.texture_height};
+        const MeshKey k{m.triangles, m.texture_data, m.bvh.root, m.triangle_count, m.texture_width, m.texture_height, stamp_of(m.bvh.root)};
         size_t g = 0;
         while (g < now.size() && !(now[g] == k)) g++;
         if (g == now.size()) now.push_back(k);
@@ -224,6 +243,7 @@ BVHNode* create_bvh_node(Triangle* triangles, int start, int count) {           
         n->right = flat[(size_t)i].right >= 0 ? heap[(size_t)flat[(size_t)i].right] : nullptr;
         heap[(size_t)i] = n;
     }
+    stamp_root(heap[0]);
     return heap[0];
 }
 
@@ -233,11 +253,17 @@ BVH create_bvh(Triangle* triangles, size_t count) {                             
     return b;
 }
 
+static void free_subtree(BVHNode* node) {
+    if (!node) return;
+    free_subtree(node->left);
+    free_subtree(node->right);
+    free(node);
+}
+
 void destroy_bvh_node(BVHNode* node) {                                              // bvh.c:69-73
     if (!node) return;
-    destroy_bvh_node(node->left);
-    destroy_bvh_node(node->right);
-    free(node);
+    forget_root(node);
+    free_subtree(node);
 }
 
 void destroy_bvh(BVH* bvh) {                                                        // bvh.c:75-78
@@ -515,6 +541,13 @@ int rt_host_wait(Scene* scene) {
 }
 
 void rt_host_set_obj_mode(int tolerant) { g_obj_mode = tolerant ? 1 : 0; }
+
+void rt_host_invalidate_scene(Scene* scene) {
+    if (!scene) return;
+    std::lock_guard<std::mutex> g(g_lock);
+    SceneState* st = state_of(scene, false);
+    if (st) st->geometries.clear();                // the next render_scene uploads every mesh again
+}
 
 void rt_host_set_save_options(float quality, int threads) { g_save_quality = quality > 100.0f ? 100.0f : quality; g_save_threads = threads; }
 

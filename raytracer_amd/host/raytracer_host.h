@@ -141,6 +141,10 @@ int rt_host_write_ppm(const Scene* scene, int index, const char* filename);
  * accepted (texture coordinate 0,0 / geometric normal where missing), negative indices count from the end.
  * In both modes lines and element counts are unbounded. */
 void rt_host_set_obj_mode(int tolerant);
+/* render_scene keeps the scene's meshes on the GPU and uploads a mesh again when its triangle array, texture or BVH
+ * is another one (a BVH rebuilt by create_bvh counts as another one even at the same address).  A caller that
+ * changes triangles or texels IN PLACE without rebuilding the BVH calls this before the next render_scene. */
+void rt_host_invalidate_scene(Scene* scene);
 /* The size and the pixels save_scene hands to its encoder for one frame (scene.c:164-165, 188-202):
  * argb receives scaled_width*scaled_height words, 0xFF000000 | r<<16 | g<<8 | b, upscaled on the GPU. */
 int rt_host_scaled_size(const Scene* scene, int* scaled_width, int* scaled_height);

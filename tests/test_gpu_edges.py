@@ -317,3 +317,55 @@ def test_tolerant_obj_through_create_mesh_renders_like_the_same_triangles_upload
     assert np.array_equal(got_rgb, want.rgb) and np.array_equal(hid, want.hit_id) and np.array_equal(sh, want.shadow)
     assert np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32))
     assert int((hid >= 0).sum()) > w * h // 10 and len(np.unique(hid)) > 100
+
+
+def test_render_scene_sees_a_bvh_rebuilt_in_place(capi, po):
+    """The reference's render_scene reads the triangles as they are at the call (scene.c:72-81).  A caller that deforms
+    mesh.triangles in place and rebuilds with destroy_bvh + create_bvh usually gets the old root address back from
+    malloc; the host library must still upload the new geometry.  Also: triangles edited in place WITHOUT a rebuild
+    are picked up after rt_host_invalidate_scene."""
+    import ctypes as C
+    import os
+    from raytracer_amd import host_api as H
+    L = H.lib()
+    w, h = 200, 120
+    m = L.create_mesh(os.path.join(H.ASSETS, "drone.obj").encode(), os.path.join(H.ASSETS, "drone.webp").encode())
+    rgba = H.mesh_texture(m)
+    scene = L.create_scene(w, h, 1000, 1, 1.0)
+    L.set_scene_camera(C.byref(scene), H.Vec3(-1.5, 1.5, -1.5), H.Vec3(0, 0.3, 0), H.Vec3(0, 1, 0), 60.0)
+    L.set_scene_light(C.byref(scene), H.Vec3(1, 1, -1), H.Vec3(1.4, 1.4, 1.4))
+    L.add_mesh_to_scene(C.byref(scene), m)
+    ident = [po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))]
+
+    def oracle_now():
+        soup = H.mesh_triangles(scene.meshes[0])
+        nodes = np.zeros(2 * soup.shape[0] + 1, capi.NODE_DTYPE)
+        used = C.c_int32(0)
+        assert capi.lib().rt_bvh_flatten_tree(C.cast(scene.meshes[0].bvh.root, C.c_void_p), nodes.ctypes.data, nodes.shape[0], C.byref(used)) == 0
+        cam = po.Camera(po.vec3(-1.5, 1.5, -1.5), po.vec3(0, 0.3, 0), po.vec3(0, 1, 0), 60.0)
+        return po.render_frame([po.HostMesh(soup, nodes[:used.value].copy(), rgba)], ident, cam, po.default_light(), w, h).rgb
+
+    L.render_scene(C.byref(scene))
+    first = H.frame_array(scene, 0)
+    assert np.array_equal(first, oracle_now())
+    # deform in place (stretch in y), rebuild the tree over the same array
+    n = int(scene.meshes[0].triangle_count)
+    tri = np.ctypeslib.as_array(C.cast(scene.meshes[0].triangles, C.POINTER(C.c_float)), shape=(n, 24))
+    old_root = C.cast(scene.meshes[0].bvh.root, C.c_void_p).value
+    tri[:, [1, 4, 7]] *= np.float32(1.5)
+    L.destroy_bvh(C.byref(scene.meshes[0].bvh))
+    scene.meshes[0].bvh = L.create_bvh(scene.meshes[0].triangles, n)
+    same_address = C.cast(scene.meshes[0].bvh.root, C.c_void_p).value == old_root
+    L.render_scene(C.byref(scene))
+    second = H.frame_array(scene, 0)
+    assert not np.array_equal(second, first)
+    assert np.array_equal(second, oracle_now()), f"stale geometry rendered (root address reused: {same_address})"
+    # in place without a rebuild: texture coordinates shifted (the tree stays valid for the positions)
+    tri[:, 9:15] += np.float32(0.25)
+    L.rt_host_invalidate_scene(C.byref(scene))
+    L.render_scene(C.byref(scene))
+    third = H.frame_array(scene, 0)
+    assert np.array_equal(third, oracle_now()) and not np.array_equal(third, second)
+    m.bvh = scene.meshes[0].bvh                    # destroy_mesh frees the tree that is alive now
+    L.destroy_mesh(C.byref(m))
+    L.destroy_scene(C.byref(scene))
