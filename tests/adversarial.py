@@ -1,0 +1,112 @@
+"""Scenes aimed at the distance culling of the default traversal (a subtree is skipped when its box is entered
+beyond closest_hit * (1 + 2^-9) + 2^-13; the reference, accel/bvh.c:106-111, skips nothing): slivers whose
+Moeller-Trumbore determinant sits just above the 1e-7 rejection threshold (ray.c:44-50), meshes far from the
+origin, a camera inside a mesh, rays grazing the zero-thickness boxes of a flat mesh, and a large triangle
+hit at a grazing angle behind a near blocker.  Used on the CPU (host build of the pixel code) and on the GPU.
+Every scene is a list of (triangle soup [k,24] f32) per mesh, placements, camera, frame size."""
+import numpy as np
+
+
+def _tri(v0, v1, v2):
+    r = np.zeros(24, np.float32)
+    r[0:3], r[3:6], r[6:9] = v0, v1, v2
+    r[9:15] = (0.1, 0.1, 0.9, 0.1, 0.5, 0.9)
+    n = np.cross(np.subtract(v1, v0), np.subtract(v2, v0))
+    ln = np.linalg.norm(n)
+    n = n / ln if ln > 0 else np.array([0.0, 1.0, 0.0])
+    r[15:18] = r[18:21] = r[21:24] = n
+    return r
+
+
+def _blob(rng, center, radius, n, size=0.3):
+    rows = []
+    for _ in range(n):
+        c = np.asarray(center) + rng.normal(size=3) * radius
+        rows.append(_tri(c, c + rng.normal(size=3) * radius * size, c + rng.normal(size=3) * radius * size))
+    return rows
+
+
+def _basis(rng):
+    d = rng.normal(size=3)
+    d /= np.linalg.norm(d)
+    a = np.cross(d, rng.normal(size=3))
+    a /= np.linalg.norm(a)
+    return d, a, np.cross(d, a)
+
+
+def scenes(po, seed=0):
+    """Yields (name, soups, transforms, camera, width, height)."""
+    rng = np.random.default_rng(seed)
+    ident = po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))
+    default_cam = po.Camera(po.vec3(-3, 3, -3), po.vec3(0, 0, 0), po.vec3(0, 1, 0), 40.0)
+
+    # slivers: long thin triangles; |a| = |e1 . (d x e2)| ~ length * width * cos, swept across the 1e-7 threshold
+    for width in (3e-7, 1e-6, 1e-5, 1e-3):
+        rows = []
+        for _ in range(300):
+            c = rng.normal(size=3) * 0.6
+            d, e, _ = _basis(rng)
+            length = 10 ** rng.uniform(-1, 0.5)
+            rows.append(_tri(c, c + d * length, c + d * length * 0.5 + e * width / length))
+        yield f"slivers width {width:g}", [rows + _blob(rng, np.zeros(3), 0.6, 100)], [ident], default_cam, 160, 90
+
+    # far from the origin: coordinates of 1e3 .. 1e4 in the triangles themselves and in the placement
+    for off in (1.0e3, 3.3e3, 1.0e4):
+        o = np.array([off, 0.5 * off, -off])
+        cam = po.Camera(po.vec3(*(o + [-3, 3, -3])), po.vec3(*o), po.vec3(0, 1, 0), 60.0)
+        plane = [_tri([-50, -1, -50], [50, -1, 50], [50, -1, -50]), _tri([-50, -1, -50], [-50, -1, 50], [50, -1, 50])]
+        yield (f"far {off:g}", [_blob(rng, o, 0.7, 300), plane],
+               [ident, po.Transform(po.vec3(o[0], o[1], o[2]), po.vec3(0.1, 0.7, 0.0))], cam, 160, 90)
+
+    # camera inside a closed-ish cloud of triangles, looking outwards through it
+    cam = po.Camera(po.vec3(0.05, 0.02, -0.03), po.vec3(1, 0.3, 0.5), po.vec3(0, 1, 0), 90.0)
+    shell = []
+    for _ in range(600):
+        d, a, b = _basis(rng)
+        c = d * rng.uniform(0.5, 2.5)
+        shell.append(_tri(c + a * 0.25, c - a * 0.2 + b * 0.2, c - b * 0.25))
+    yield "camera inside", [shell], [ident], cam, 160, 90
+
+    # grazing rays along a flat mesh (boxes of zero thickness), other geometry just above it
+    n = 12
+    xs = np.linspace(-6, 6, n + 1)
+    flat = []
+    for j in range(n):
+        for i in range(n):
+            p = lambda a_, b_: [xs[a_], 0.0, xs[b_]]                     # noqa: E731
+            flat += [_tri(p(i, j), p(i + 1, j + 1), p(i + 1, j)), _tri(p(i, j), p(i, j + 1), p(i + 1, j + 1))]
+    for hgt in (1e-1, 1e-3, 1e-5):
+        cam = po.Camera(po.vec3(-5.5, hgt, 0.013), po.vec3(5.0, 0.0, 0.4), po.vec3(0, 1, 0), 30.0)
+        yield f"grazing flat mesh height {hgt:g}", [flat, _blob(rng, [0, 0.05, 0], 1.5, 200, size=0.1)], [ident, ident], cam, 160, 90
+        yield (f"grazing flat mesh height {hgt:g}, one mesh", [flat + _blob(rng, [0, 0.05, 0], 1.5, 200, size=0.1)], [ident], cam, 160, 90)
+
+    # a triangle in general position hit at a grazing angle g (its distance then carries a relative error of
+    # about 3e-7 / g) behind a blocker that faces the camera; the view is as narrow as the grazing band
+    for k in range(6):
+        dist = 10 ** rng.uniform(0.7, 2.0)
+        size = 10 ** rng.uniform(-0.5, 0.4)
+        g = 10 ** rng.uniform(-6.5, -4.0)
+        d, a, b = _basis(rng)
+        pos = rng.normal(size=3)
+        center = pos + d * dist
+        dp = d + g * b
+        dp /= np.linalg.norm(dp)
+        rows = [_tri(center - dp * size - a * size, center + dp * size - a * size * 0.2, center + a * size)]
+        delta = (1.2 * size + 0.004 * dist) * rng.uniform(1.0, 1.5)
+        bc = pos + d * (dist - delta)
+        rows.append(_tri(bc - a * size - b * size, bc + a * size - b * size, bc + b * size))
+        for _ in range(30):
+            c = center + a * rng.uniform(6, 18) * size * rng.choice([-1, 1]) + b * rng.uniform(-3, 3) + d * rng.uniform(-2, 2)
+            rows.append(_tri(c, c + rng.normal(size=3) * 0.2, c + rng.normal(size=3) * 0.2))
+        fov = float(np.degrees(2 * np.arctan(4 * size * g / dist)))
+        cam = po.Camera(po.vec3(*pos), po.vec3(*center), po.vec3(*b), fov)
+        yield f"grazing triangle g={g:.2g} behind a blocker", [rows], [ident], cam, 96, 54
+
+
+def build(po, soups, texture):
+    """Oracle-side meshes (reference build of every soup)."""
+    out = []
+    for s in soups:
+        t, nodes = po.build_bvh(np.asarray(s, np.float32))
+        out.append(po.HostMesh(t, nodes, texture))
+    return out

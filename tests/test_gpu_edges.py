@@ -369,3 +369,34 @@ def test_render_scene_sees_a_bvh_rebuilt_in_place(capi, po):
     m.bvh = scene.meshes[0].bvh                    # destroy_mesh frees the tree that is alive now
     L.destroy_mesh(C.byref(m))
     L.destroy_scene(C.byref(scene))
+
+
+def test_culling_keeps_the_reference_result_on_adversarial_scenes_gpu(capi, po):
+    """The scenes of tests/adversarial.py on the GPU: default mode (ordered, distance-culled) and
+    RT_FLAG_REFERENCE_ORDER against the oracle's reference loop, every plane bit for bit; and through
+    rt_render_frames (the throughput kernel) for the RGB plane."""
+    import torch
+    import adversarial
+    tex = checker()
+    cam0, light = camera_light(capi, po)
+    n = 0
+    for name, soups, tfs, cam, w, h in adversarial.scenes(po, seed=5):
+        meshes = adversarial.build(po, soups, tex)
+        want = po.render_frame(meshes, tfs, cam, po.default_light(), w, h)
+        ccam = capi.Camera(capi.Vec3(*cam.position.tup()), capi.Vec3(*cam.look_at.tup()), capi.Vec3(*cam.up.tup()), cam.fov)
+        with capi.Context(0) as c:
+            for m in meshes:
+                c.upload_mesh(m.tris, m.nodes, m.rgba)
+            ctf = conv(capi, tfs)
+            for flags in (0, capi.RT_FLAG_REFERENCE_ORDER):
+                rgb, hid, ht, sh = c.render_host(ccam, light, ctf, w, h, flags=flags)
+                mode = "reference order" if flags else "default"
+                assert np.array_equal(hid, want.hit_id), f"{name}: {(hid != want.hit_id).sum()} hit ids differ ({mode})"
+                assert np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32)), f"{name}: t ({mode})"
+                assert np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb), f"{name}: shading ({mode})"
+            out = torch.zeros((2, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            c.render_frames(ccam, light, [ctf, ctf], w, h, out)
+            c.sync()
+            assert np.array_equal(out[0].cpu().numpy(), want.rgb) and np.array_equal(out[1].cpu().numpy(), want.rgb), name
+        n += 1
+    assert n >= 20

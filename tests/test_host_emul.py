@@ -344,3 +344,27 @@ def test_priorities_encode_the_reference_tie_order(po, meshes, em_default):
         leaves = m.nodes[m.nodes["left"] < 0]
         for s0, c in zip(leaves["start"], leaves["count"]):
             assert (np.diff(pr[s0:s0 + c].astype(np.int64)) < 0).all()
+
+
+# ------------------------------------------------------------------------------ scenes aimed at the distance culling
+def test_culling_keeps_the_reference_result_on_adversarial_scenes(po):
+    """Default traversal (ordered, distance-culled, regrouped tree) and reference-order traversal of the product's
+    pixel code against the oracle's reference loop on slivers at the determinant threshold, coordinates of 1e3..1e4,
+    a camera inside a mesh, rays grazing zero-thickness boxes and grazing hits behind a blocker: all planes identical."""
+    import adversarial
+    tex = checker()
+    n = 0
+    for name, soups, tfs, cam, w, h in adversarial.scenes(po, seed=5):
+        meshes = adversarial.build(po, soups, tex)
+        s = emul.Scene(regroup=True)
+        for m in meshes:
+            assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+        want = po.render_frame(meshes, tfs, cam, po.default_light(), w, h)
+        for full in (False, True):
+            got = s.render(cam, po.default_light(), tfs, w, h, full=full)
+            for k, ref in (("hit_id", want.hit_id), ("shadow", want.shadow), ("rgb", want.rgb)):
+                assert np.array_equal(got[k], ref), f"{name}: {k} differs ({'reference order' if full else 'default'})"
+            assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t)), name
+        s.close()
+        n += 1
+    assert n >= 20
