@@ -2,7 +2,8 @@
 # Builds the C-ABI library, the host library and examples/drone_animation.c with the address and undefined-behaviour sanitizers on the HOST side
 # only (device code is compiled as usual) into build/asan/, for a run on a GPU box:
 #     bash scripts/asan_driver.sh            (here, no GPU needed)
-#     ASAN_OPTIONS=detect_leaks=0 ./build/asan/drone_animation raytracer_amd/assets out.webp 4      (on the box)
+#     ASAN_OPTIONS=detect_leaks=0:quarantine_size_mb=0 ./build/asan/drone_animation raytracer_amd/assets out.webp 4      (on the box;
+#         with the default quarantine the sanitizer recycles released device memory from inside the HSA runtime's exit handler and aborts)
 #     ASAN_OPTIONS=detect_leaks=0 ./build/asan/abi_check                                             (on the box)
 # The sanitizer runtime is the one of the ROCm clang, so all three pieces are compiled with it.
 set -eu
