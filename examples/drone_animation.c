@@ -6,9 +6,10 @@
  * meshes, per frame the placements of raytracer.c:41-53, render_scene + next_frame, then save_scene.
  * Nothing in it names a GPU: which device renders is the library's business.
  *
- *   drone_animation <assets dir> <out.webp> [frames in flight] [ppm prefix]
+ *   drone_animation <assets dir> <out.webp> [frames in flight] [ppm prefix] [gpus]
  *
- * With a ppm prefix, frames 0, 45 and 95 are also written as <prefix>_<frame>.ppm.
+ * With a ppm prefix ("-" for none), frames 0, 45 and 95 are also written as <prefix>_<frame>.ppm.  With a GPU count
+ * above one, frame f is rendered on GPU f mod gpus (use it with two or more frames in flight).
  * Build: gcc -std=c11 -O2 -I raytracer_amd/host examples/drone_animation.c \
  *            -L raytracer_amd/host -lraytracer_host -Wl,-rpath,$PWD/raytracer_amd/host -lm
  */
@@ -31,13 +32,20 @@ static double seconds(void) {
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        fprintf(stderr, "usage: %s <assets dir> <out.webp> [frames in flight] [ppm prefix]\n", argv[0]);
+        fprintf(stderr, "usage: %s <assets dir> <out.webp> [frames in flight] [ppm prefix] [gpus]\n", argv[0]);
         return 2;
     }
     const char* assets = argv[1];
     const char* out = argv[2];
     const int in_flight = argc > 3 ? atoi(argv[3]) : 1;
-    const char* ppm = argc > 4 ? argv[4] : NULL;
+    const char* ppm = argc > 4 && argv[4][0] != '-' ? argv[4] : NULL;
+    const int gpus = argc > 5 ? atoi(argv[5]) : 1;
+    if (gpus > 1) {
+        int list[64];
+        if (gpus > 64) { fprintf(stderr, "at most 64 GPUs\n"); return 2; }
+        for (int i = 0; i < gpus; i++) list[i] = i;
+        if (rt_host_set_gpus(list, gpus) != 0) { fprintf(stderr, "this machine does not have %d GPUs\n", gpus); return 1; }
+    }
 
     Scene scene = create_scene(800, 600, 4000, 24, 0.9f);
     set_scene_camera(&scene, (Vec3){-3.0f, 3.0f, -3.0f}, (Vec3){0.0f, 0.0f, 0.0f}, (Vec3){0.0f, 1.0f, 0.0f}, 60.0f);
@@ -80,8 +88,8 @@ int main(int argc, char** argv) {
     }
     save_scene(&scene, out);
     const double t2 = seconds();
-    printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"frames_in_flight\": %d, \"render_s\": %.4f, \"save_s\": %.4f}\n",
-           scene.frame_count, scene.width, scene.height, in_flight, t1 - t0, t2 - t1);
+    printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"frames_in_flight\": %d, \"gpus\": %d, \"render_s\": %.4f, \"save_s\": %.4f}\n",
+           scene.frame_count, scene.width, scene.height, in_flight, gpus, t1 - t0, t2 - t1);
 
 done:
     for (int i = 0; i < loaded; i++) destroy_mesh(&meshes[i]);

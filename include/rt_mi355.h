@@ -212,6 +212,24 @@ int rt_render_frame_sampled_strips(rt_ctx* ctx, const rt_camera* camera, const r
                                    int32_t n_transforms, int32_t width, int32_t height, int32_t samples_per_pixel, uint32_t seed,
                                    int32_t strip_stride, int32_t strip_offset, uint32_t flags, void* d_rgb, void* d_hit_id, void* stream);
 
+/* ---- the animation over several GPUs of one process ---------------------------------------- */
+/* The reference's frame loop (raytracer.c:40-57: place the meshes, render_scene, next_frame, for every frame) dealt
+ * over n_ctx contexts, normally one per GPU: frame f is rendered by ctxs[f mod n_ctx] (frames are independent: each
+ * reads its own placements and writes its own buffer), and all frames are gathered on the GPU of ctxs[0], where
+ * save_scene's upscale and encoder consume them (scene.c:186-206): frame f ends up at (uint8_t*)d_rgb + f*frame_stride,
+ * d_rgb being memory of ctxs[0]'s GPU that holds n_frames images.  Every context must hold the same meshes (upload the
+ * scene to each).  transforms holds n_frames * n_transforms entries, frame after frame.  Batches of up to RT_MAX_BATCH
+ * frames go through rt_render_frames on each context's own stream; a batch rendered on another GPU is copied to its
+ * place by peer-to-peer copies (xGMI between the GPUs of a node) queued behind its kernel, while that GPU's next batch
+ * renders; ctxs[0] renders in place.  No collective is involved: the gather is one point-to-point stream per GPU.
+ * The call returns when all frames are in d_rgb.  n_frames may be any number (0: nothing to do); with n_ctx = 1 the
+ * result is rt_render_frames' over consecutive batches.  Several contexts on the same GPU are allowed (rehearsal).
+ * Errors are reported through ctxs[0] (rt_last_error).  rt_device_count: GPUs visible to the process. */
+int rt_render_frames_sharded(rt_ctx* const* ctxs, int32_t n_ctx, const rt_camera* camera, const rt_light* light,
+                             const rt_transform* transforms, int32_t n_frames, int32_t n_transforms,
+                             int32_t width, int32_t height, void* d_rgb, size_t frame_stride);
+int rt_device_count(void);
+
 /* render_scene for a scene whose mesh list is long: the reference's Scene.meshes may hold any number of
  * Mesh values (add_mesh_to_scene, scene.c:31-35), for example the same triangles and BVH under thousands of
  * transforms, and tests every ray against every one of them (scene.c:72-108, 124-139).  Here the uploaded

@@ -62,7 +62,7 @@ EXPORTS = [
     "rt_mesh_upload", "rt_mesh_upload_tree", "rt_scene_clear", "rt_mesh_count", "rt_render_frame",
     "rt_render_frame_host", "rt_sync", "rt_last_kernel_ms", "rt_last_counters", "rt_set_option", "rt_get_option",
     "rt_set_trace_buffer", "rt_render_frames", "rt_scaled_size", "rt_upscale_frames", "rt_upscale_frame_host",
-    "rt_render_frame_sampled", "rt_render_frame_instanced", "rt_render_frame_instanced_host", "rt_render_frames_noalloc",
+    "rt_render_frame_sampled", "rt_render_frame_instanced", "rt_render_frame_instanced_host", "rt_render_frames_noalloc", "rt_render_frames_sharded", "rt_device_count",
 ]
 
 _lib = None
@@ -117,6 +117,9 @@ def lib():
         L.rt_render_frames.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, i32,
                                        vp, C.c_size_t, vp]
         L.rt_render_frames_noalloc.argtypes = L.rt_render_frames.argtypes
+        L.rt_render_frames_sharded.argtypes = [C.POINTER(vp), i32, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32, i32,
+                                               vp, C.c_size_t]
+        L.rt_device_count.argtypes = []
         L.rt_render_frame_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, i32, i32,
                                               u32, u32, vp, vp, vp]
         L.rt_strip_rows.argtypes = [i32, i32, i32]
@@ -175,6 +178,26 @@ def build_bvh(tris: np.ndarray):
     if st != RT_OK:
         raise RtError(st)
     return t, nodes[:used.value].copy()
+
+
+def device_count() -> int:
+    return int(lib().rt_device_count())
+
+
+def render_frames_sharded(contexts, camera: Camera, light: Light, transforms, width: int, height: int, rgb,
+                          frame_stride: Optional[int] = None):
+    """rt_render_frames_sharded: frame f by contexts[f mod N], all frames gathered in `rgb` ([n_frames, h, w, 3] uint8 on
+    contexts[0]'s GPU).  transforms[f] are the placements of frame f.  Returns when the frames are there."""
+    n = len(transforms)
+    m = len(transforms[0]) if n else 0
+    flat = [t for frame in transforms for t in frame]
+    arr = (Transform * max(len(flat), 1))(*flat)
+    handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    stride = int(frame_stride) if frame_stride is not None else int(width) * int(height) * 3
+    st = lib().rt_render_frames_sharded(handles, len(contexts), C.byref(camera), C.byref(light), arr, n, m, int(width), int(height),
+                                        _dev_ptr(rgb), stride)
+    if st != RT_OK:
+        raise RtError(st, lib().rt_last_error(contexts[0]._h).decode() if contexts else "")
 
 
 def _dev_ptr(x) -> Optional[int]:

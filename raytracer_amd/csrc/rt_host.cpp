@@ -115,6 +115,12 @@ struct rt_ctx {
     size_t ring_pixels[kRingSlots] = {};
     bool ring_used[kRingSlots] = {};
     unsigned ring_seq = 0;
+    // rt_render_frames_sharded: this context's frames wait here (two slots of up to RT_MAX_BATCH images) for their copy to the
+    // gathering GPU
+    uint8_t* shard_buf[2] = {};
+    size_t shard_bytes[2] = {};
+    hipEvent_t shard_done[2] = {};
+    bool shard_used[2] = {};
     std::vector<InstanceCache> inst_cache;
     StandingTlas standing;         // rt_render_frame_instanced: the hierarchy over the instances, kept between calls
     int keep_hierarchy = 1;
@@ -419,6 +425,10 @@ int rt_ctx_destroy(rt_ctx* ctx) {
         if (ctx->ring_stream[i]) { (void)hipStreamSynchronize(ctx->ring_stream[i]); (void)hipStreamDestroy(ctx->ring_stream[i]); }
         if (ctx->ring_done[i]) (void)hipEventDestroy(ctx->ring_done[i]);
         if (ctx->ring_rgb[i]) (void)hipFree(ctx->ring_rgb[i]);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (ctx->shard_done[i]) { if (ctx->shard_used[i]) (void)hipEventSynchronize(ctx->shard_done[i]); (void)hipEventDestroy(ctx->shard_done[i]); }
+        if (ctx->shard_buf[i]) (void)hipFree(ctx->shard_buf[i]);
     }
     if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
@@ -975,6 +985,95 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
     RT_HIP(ctx, hipEventRecord(ctx->inst_done[slot], s));
     ctx->inst_used[slot] = true;
     return RT_OK;
+}
+
+// ---- the frame loop over several GPUs of one process -------------------------------------------------------------
+int rt_render_frames_sharded(rt_ctx* const* ctxs, int32_t n_ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,
+                             int32_t n_frames, int32_t n_transforms, int32_t width, int32_t height, void* d_rgb, size_t frame_stride) {
+    if (!ctxs || n_ctx < 1 || n_ctx > 64) return RT_ERR_INVALID;
+    for (int32_t r = 0; r < n_ctx; r++) if (!ctxs[r]) return RT_ERR_INVALID;
+    rt_ctx* root = ctxs[0];
+    if (!camera || !light || !d_rgb) return fail(root, RT_ERR_INVALID, "camera, light and d_rgb are required");
+    if (n_frames < 0) return fail(root, RT_ERR_INVALID, "negative frame count");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(root, RT_ERR_INVALID, "bad frame size");
+    const size_t image = (size_t)width * (size_t)height * 3;
+    if (frame_stride < image) return fail(root, RT_ERR_INVALID, "frame_stride smaller than one image");
+    if (n_frames == 0) return RT_OK;
+    for (int32_t r = 0; r < n_ctx; r++) {
+        if ((int32_t)ctxs[r]->meshes.size() != n_transforms) return fail(root, RT_ERR_INVALID, "every context needs the scene's meshes uploaded (one transform per mesh)");
+        for (int32_t q = 0; q < r; q++) if (ctxs[q] == ctxs[r]) return fail(root, RT_ERR_INVALID, "the same context listed twice");
+    }
+    if (n_transforms > 0 && !transforms && n_frames > 0) return fail(root, RT_ERR_INVALID, "transforms missing");
+    uint8_t* out = (uint8_t*)d_rgb;
+    std::vector<rt_transform> tf;
+    // direct copies between the GPUs where the hardware allows them (otherwise the runtime stages the copies)
+    for (int32_t r = 1; r < n_ctx; r++) {
+        if (ctxs[r]->device == root->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ctxs[r]->device, root->device) == hipSuccess && can && hipSetDevice(ctxs[r]->device) == hipSuccess)
+            (void)hipDeviceEnablePeerAccess(root->device, 0);
+        (void)hipGetLastError();                                    // "already enabled" is not an error here
+    }
+    // Frame f belongs to context f mod n_ctx.  Round after round every context gets its next batch: the kernel on its
+    // own stream, then (contexts other than the first) one copy per frame from its staging slot to the frame's place on
+    // the gathering GPU, queued behind the kernel on the same stream, so that the copies of one batch run over the
+    // GPU's link to the gathering GPU while the next batch renders.  The first context renders in place.
+    const int32_t share_max = (n_frames + n_ctx - 1) / n_ctx;
+    int status = RT_OK;
+    for (int32_t k0 = 0, round = 0; k0 < share_max && status == RT_OK; k0 += RT_MAX_BATCH, round++) {
+        for (int32_t r = 0; r < n_ctx && status == RT_OK; r++) {
+            rt_ctx* c = ctxs[r];
+            const int32_t first = r + k0 * n_ctx;                    // first frame of this batch
+            if (first >= n_frames) continue;
+            int32_t nb = (n_frames - first + n_ctx - 1) / n_ctx;     // frames first, first + n_ctx, ... below n_frames
+            if (nb > RT_MAX_BATCH) nb = RT_MAX_BATCH;
+            tf.resize((size_t)nb * (size_t)(n_transforms > 0 ? n_transforms : 0));
+            for (int32_t j = 0; j < nb; j++)
+                for (int32_t m = 0; m < n_transforms; m++)
+                    tf[(size_t)j * n_transforms + m] = transforms[(size_t)(first + j * n_ctx) * n_transforms + m];
+            if (r == 0) {
+                status = rt_render_frames(c, camera, light, tf.data(), nb, n_transforms, width, height, out + (size_t)first * frame_stride,
+                                          frame_stride * (size_t)n_ctx, nullptr);
+                if (status != RT_OK && c != root) root->err = c->err;
+                continue;
+            }
+            const int slot = round & 1;
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess && c->shard_used[slot]) { e = hipEventSynchronize(c->shard_done[slot]); c->shard_used[slot] = false; }
+            if (e == hipSuccess && !c->shard_done[slot]) e = hipEventCreateWithFlags(&c->shard_done[slot], hipEventDisableTiming);
+            const size_t need = image * (size_t)nb;
+            if (e == hipSuccess && need > c->shard_bytes[slot]) {
+                if (c->shard_buf[slot]) (void)hipFree(c->shard_buf[slot]);
+                c->shard_buf[slot] = nullptr; c->shard_bytes[slot] = 0;
+                e = hipMalloc((void**)&c->shard_buf[slot], image * (size_t)RT_MAX_BATCH);
+                if (e == hipSuccess) c->shard_bytes[slot] = image * (size_t)RT_MAX_BATCH;
+            }
+            if (e != hipSuccess) { status = hip_fail(root, e, "staging buffer of a sharded frame loop"); break; }
+            status = rt_render_frames(c, camera, light, tf.data(), nb, n_transforms, width, height, c->shard_buf[slot], image, nullptr);
+            if (status != RT_OK) { root->err = c->err; break; }
+            for (int32_t j = 0; j < nb && e == hipSuccess; j++)
+                e = hipMemcpyPeerAsync(out + (size_t)(first + j * n_ctx) * frame_stride, root->device, c->shard_buf[slot] + (size_t)j * image, c->device,
+                                       image, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(c->shard_done[slot], c->stream);
+            if (e != hipSuccess) { status = hip_fail(root, e, "copy of a frame to the gathering GPU"); break; }
+            c->shard_used[slot] = true;
+        }
+    }
+    // the frames are in d_rgb when the call returns (also after a failure nothing is left in flight)
+    for (int32_t r = 0; r < n_ctx; r++) {
+        hipError_t e = hipSetDevice(ctxs[r]->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctxs[r]->stream);
+        ctxs[r]->shard_used[0] = ctxs[r]->shard_used[1] = false;
+        if (e != hipSuccess && status == RT_OK) status = hip_fail(root, e, "waiting for a GPU of the sharded frame loop");
+    }
+    (void)hipSetDevice(root->device);
+    return status;
+}
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
 }
 
 int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_transform* transforms,

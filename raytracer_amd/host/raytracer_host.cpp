@@ -53,10 +53,16 @@ uint64_t stamp_of(const void* root) {
     auto it = g_root_stamp.find(root);
     return it == g_root_stamp.end() ? 0 : it->second;       // 0: a tree the caller linked together itself
 }
-struct SceneState {
+// One GPU that renders frames of a scene.  A scene normally has one; after rt_host_set_gpus it has one per listed
+// device and frame f goes to entry f mod n (frames are independent, raytracer.c:40-57).
+struct GpuState {
     rt_ctx* ctx = nullptr;
+    int device = 0;
     int in_flight = 1;                    // the context's "frames_in_flight" as last set
     std::vector<MeshKey> geometries;      // distinct (triangles, BVH, texture) uploaded, in upload order
+};
+struct SceneState {
+    std::vector<GpuState> gpus;
     int last_status = 0;
 };
 std::mutex g_lock;
@@ -64,6 +70,7 @@ std::map<const void*, SceneState> g_states;
 std::map<const void*, void*> g_pinned_frames;    // Scene.frames array -> the page-locked block its frames live in
 int g_device = -1;
 int g_in_flight = 1;                              // rt_host_set_frames_in_flight
+std::vector<int> g_gpu_list;                      // rt_host_set_gpus; empty = the one device of pick_device()
 
 int pick_device() {
     if (g_device >= 0) return g_device;
@@ -75,16 +82,19 @@ SceneState* state_of(const Scene* scene, bool create) {
     auto it = g_states.find((const void*)scene->frames);
     if (it != g_states.end()) return &it->second;
     if (!create) return nullptr;
-    return &g_states[(const void*)scene->frames];
+    SceneState& st = g_states[(const void*)scene->frames];
+    if (g_gpu_list.empty()) { st.gpus.resize(1); st.gpus[0].device = pick_device(); }
+    else { st.gpus.resize(g_gpu_list.size()); for (size_t i = 0; i < st.gpus.size(); i++) st.gpus[i].device = g_gpu_list[i]; }
+    return &st;
 }
 
 // Brings the GPU's geometry list in line with the scene's meshes.  Scene.meshes may repeat a geometry
 // (the same triangle array, BVH and texture under another transform): each distinct one is uploaded once
 // and geometry_of[i] says which one mesh i uses.
-int sync_scene(Scene* scene, SceneState& st, std::vector<int32_t>& geometry_of) {
+int sync_scene(Scene* scene, GpuState& st, std::vector<int32_t>& geometry_of) {
     if (!st.ctx) {
-        int rc = rt_ctx_create(pick_device(), &st.ctx);
-        if (rc != RT_OK) { fprintf(stderr, "render_scene: cannot open GPU %d: %s\n", pick_device(), rt_status_string(rc)); return rc; }
+        int rc = rt_ctx_create(st.device, &st.ctx);
+        if (rc != RT_OK) { fprintf(stderr, "render_scene: cannot open GPU %d: %s\n", st.device, rt_status_string(rc)); return rc; }
     }
     std::vector<MeshKey> now;
     geometry_of.assign(scene->mesh_count, -1);
@@ -111,15 +121,22 @@ int sync_scene(Scene* scene, SceneState& st, std::vector<int32_t>& geometry_of) 
 
 // Waits for the frames render_scene left in flight (g_lock held by the caller).
 int wait_frames(SceneState* st) {
-    if (!st || !st->ctx || st->in_flight <= 1) return RT_OK;
-    const int rc = rt_sync(st->ctx, nullptr);
-    if (rc != RT_OK) { fprintf(stderr, "render_scene: %s (%s)\n", rt_status_string(rc), rt_last_error(st->ctx)); st->last_status = rc; }
+    if (!st) return RT_OK;
+    int rc = RT_OK;
+    for (GpuState& g : st->gpus) {
+        if (!g.ctx || g.in_flight <= 1) continue;
+        const int r = rt_sync(g.ctx, nullptr);
+        if (r != RT_OK) { fprintf(stderr, "render_scene: %s (%s)\n", rt_status_string(r), rt_last_error(g.ctx)); st->last_status = r; rc = r; }
+    }
     return rc;
 }
 
 int render_into(Scene* scene, uint8_t* rgb, int32_t* hit_id, float* hit_t, uint8_t* shadow) {
     std::lock_guard<std::mutex> g(g_lock);
-    SceneState* st = state_of(scene, true);
+    SceneState* state = state_of(scene, true);
+    // the GPU of this frame: frame f on entry f mod n of the scene's GPU list
+    const size_t turn = scene->current_frame > 0 ? (size_t)scene->current_frame % state->gpus.size() : 0;
+    GpuState* st = &state->gpus[turn];
     std::vector<int32_t> geometry_of;
     int rc = sync_scene(scene, *st, geometry_of);
     const int in_flight = (hit_id || hit_t || shadow) ? 1 : g_in_flight;
@@ -150,7 +167,7 @@ int render_into(Scene* scene, uint8_t* rgb, int32_t* hit_id, float* hit_t, uint8
         }
         if (rc != RT_OK) fprintf(stderr, "render_scene: %s (%s)\n", rt_status_string(rc), rt_last_error(st->ctx));
     }
-    st->last_status = rc;
+    state->last_status = rc;
     return rc;
 }
 
@@ -462,7 +479,7 @@ void destroy_scene(Scene* scene) {                                              
         auto it = g_states.find((const void*)scene->frames);
         if (it != g_states.end()) {
             (void)wait_frames(&it->second);                    // copies into scene->frames may still be queued
-            if (it->second.ctx) rt_ctx_destroy(it->second.ctx);
+            for (GpuState& gpu : it->second.gpus) if (gpu.ctx) rt_ctx_destroy(gpu.ctx);
             g_states.erase(it);
         }
     }
@@ -520,16 +537,26 @@ int rt_host_upscale_frame(Scene* scene, int index, uint32_t* argb) {            
     if (rc != RT_OK) return rc;
     std::lock_guard<std::mutex> g(g_lock);
     SceneState* st = state_of(scene, true);
-    if (!st->ctx) {
-        rc = rt_ctx_create(pick_device(), &st->ctx);
-        if (rc != RT_OK) { fprintf(stderr, "rt_host_upscale_frame: cannot open GPU %d: %s\n", pick_device(), rt_status_string(rc)); st->last_status = rc; return rc; }
+    GpuState& first = st->gpus[0];                   // the encoder's side: the first GPU of the scene's list
+    if (!first.ctx) {
+        rc = rt_ctx_create(first.device, &first.ctx);
+        if (rc != RT_OK) { fprintf(stderr, "rt_host_upscale_frame: cannot open GPU %d: %s\n", first.device, rt_status_string(rc)); st->last_status = rc; return rc; }
     }
     rc = wait_frames(st);
     if (rc != RT_OK) return rc;
-    rc = rt_upscale_frame_host(st->ctx, scene->frames[index], scene->width, scene->height, sw, sh, argb);
-    if (rc != RT_OK) fprintf(stderr, "rt_host_upscale_frame: %s (%s)\n", rt_status_string(rc), rt_last_error(st->ctx));
+    rc = rt_upscale_frame_host(first.ctx, scene->frames[index], scene->width, scene->height, sw, sh, argb);
+    if (rc != RT_OK) fprintf(stderr, "rt_host_upscale_frame: %s (%s)\n", rt_status_string(rc), rt_last_error(first.ctx));
     st->last_status = rc;
     return rc;
+}
+
+int rt_host_set_gpus(const int* devices, int n) {
+    if (n < 0 || n > 64 || (n > 0 && !devices)) return RT_ERR_INVALID;
+    const int have = rt_device_count();
+    for (int i = 0; i < n; i++) if (devices[i] < 0 || devices[i] >= have) return RT_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> g(g_lock);
+    g_gpu_list.assign(devices, devices + n);
+    return RT_OK;
 }
 
 void rt_host_set_frames_in_flight(int n) { std::lock_guard<std::mutex> g(g_lock); g_in_flight = n < 1 ? 1 : (n > 8 ? 8 : n); }
@@ -546,7 +573,7 @@ void rt_host_invalidate_scene(Scene* scene) {
     if (!scene) return;
     std::lock_guard<std::mutex> g(g_lock);
     SceneState* st = state_of(scene, false);
-    if (st) st->geometries.clear();                // the next render_scene uploads every mesh again
+    if (st) for (GpuState& gpu : st->gpus) gpu.geometries.clear();      // the next render_scene uploads every mesh again
 }
 
 void rt_host_set_save_options(float quality, int threads) { g_save_quality = quality > 100.0f ? 100.0f : quality; g_save_threads = threads; }

@@ -124,6 +124,12 @@ uint32_t bicubic_interpolate(unsigned char* frame, float x, float y, int width, 
 /* ---- additions that the reference does not have ---- */
 /* GPU used by scenes created afterwards on this thread's process (default 0, or $RT_DEVICE). */
 void rt_host_set_device(int device);
+/* Scenes created afterwards deal their frames over several GPUs: render_scene of frame f (scene->current_frame) runs on
+ * devices[f mod n], each with its own copy of the scene's meshes, and writes scene->frames[f] as always.  Frames are
+ * independent (raytracer.c:40-57), so with rt_host_set_frames_in_flight(k >= 2) the GPUs work side by side; save_scene
+ * and rt_host_upscale_frame use devices[0].  A device may be listed more than once.  n = 0 returns to the single device
+ * of rt_host_set_device.  Returns 0 or a negative rt_status (unknown device: RT_ERR_NO_DEVICE). */
+int rt_host_set_gpus(const int* devices, int n);
 /* Status of the most recent render_scene() on this scene: 0 or a negative rt_status. */
 int rt_host_last_status(const Scene* scene);
 /* Debug planes of the most recent render_scene(): any pointer may be NULL.

@@ -88,7 +88,7 @@ EXPORTS = [
     "sample_mesh_texture", "create_bvh_node", "create_bvh", "destroy_bvh_node", "destroy_bvh", "intersect_bvh", "create_camera",
     "create_directional_light", "rt_host_set_device", "rt_host_last_status", "rt_host_render_debug",
     "rt_host_demo_animation", "rt_host_write_ppm", "rt_host_scaled_size", "rt_host_upscale_frame",
-    "rt_host_set_obj_mode", "rt_host_invalidate_scene", "rt_host_animation_has_webp", "rt_host_animation_open", "rt_host_animation_add",
+    "rt_host_set_obj_mode", "rt_host_invalidate_scene", "rt_host_set_gpus", "rt_host_animation_has_webp", "rt_host_animation_open", "rt_host_animation_add",
     "rt_host_animation_close", "rt_host_set_save_options", "rt_host_set_frames_in_flight", "rt_host_wait",
 ]
 
@@ -161,6 +161,8 @@ def lib():
         L.rt_host_set_frames_in_flight.argtypes = [C.c_int]
         L.rt_host_wait.restype = C.c_int
         L.rt_host_wait.argtypes = [C.POINTER(Scene)]
+        L.rt_host_set_gpus.restype = C.c_int
+        L.rt_host_set_gpus.argtypes = [C.POINTER(C.c_int), C.c_int]
         L.rt_host_invalidate_scene.restype = None
         L.rt_host_invalidate_scene.argtypes = [C.POINTER(Scene)]
         L.rt_host_set_obj_mode.restype = None

@@ -1,0 +1,93 @@
+"""The frame loop over several contexts of one process: rt_render_frames_sharded through the C ABI and
+rt_host_set_gpus through the reference's host API.  The GPU box has one GPU, so "several GPUs" is rehearsed with
+several contexts on device 0 -- the dealing of frames, the staging slots and the copies to the gathering device
+are the code an 8-GPU node runs; what is not covered here is the xGMI transfer itself (hardware-unmeasured)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sharded_frame_loop_equals_the_batched_one():
+    import torch
+    from raytracer_amd import capi, demo
+    w, h = 160, 90
+    scenes = [demo.DemoScene(0) for _ in range(3)]
+    try:
+        cam, light = scenes[0].camera, scenes[0].light
+        assert capi.device_count() >= 1
+        for n_frames in (1, 16, 40, 53):
+            tfs = [scenes[0].transforms(f) for f in range(n_frames)]
+            want = torch.zeros((n_frames, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            for b in range(0, n_frames, 16):
+                scenes[0].ctx.render_frames(cam, light, tfs[b:b + 16], w, h, want[b:b + 16])
+            scenes[0].ctx.sync()
+            for n_ctx in (1, 2, 3):
+                got = torch.full((n_frames, h, w, 3), 9, dtype=torch.uint8, device="cuda:0")
+                capi.render_frames_sharded([s.ctx for s in scenes[:n_ctx]], cam, light, tfs, w, h, got)
+                assert torch.equal(got, want), f"{n_frames} frames over {n_ctx} contexts"
+        # a padded frame stride, and nothing to do
+        tfs = [scenes[0].transforms(f) for f in range(7)]
+        stride = w * h * 3 + 256
+        flat = torch.zeros(7 * stride, dtype=torch.uint8, device="cuda:0")
+        capi.render_frames_sharded([s.ctx for s in scenes[:2]], cam, light, tfs, w, h, flat, frame_stride=stride)
+        for f in range(7):
+            assert torch.equal(flat[f * stride:f * stride + w * h * 3].reshape(h, w, 3), want[f])
+            assert int(flat[f * stride + w * h * 3:(f + 1) * stride].sum()) == 0
+        capi.render_frames_sharded([scenes[0].ctx], cam, light, [], w, h, flat)
+        # refusals: the same context twice, a context without the scene
+        with pytest.raises(capi.RtError):
+            capi.render_frames_sharded([scenes[0].ctx, scenes[0].ctx], cam, light, tfs, w, h, flat, frame_stride=stride)
+        with capi.Context(0) as empty:
+            with pytest.raises(capi.RtError):
+                capi.render_frames_sharded([scenes[0].ctx, empty], cam, light, tfs, w, h, flat, frame_stride=stride)
+    finally:
+        for s in scenes:
+            s.close()
+
+
+def test_host_api_deals_frames_over_a_gpu_list():
+    """rt_host_set_gpus: the reference driver's loop with frame f on list entry f mod n (two entries, both device 0, four
+    frames in flight); the first 12 frames of the animation equal the compiled reference's, hash for hash."""
+    from raytracer_amd import host_api as H
+    hashes = json.load(open(os.path.join(GOLDEN, "animation_hashes.json")))
+    L = H.lib()
+    assert L.rt_host_set_gpus((C.c_int * 2)(0, 99), 2) != 0            # no such device
+    assert L.rt_host_set_gpus((C.c_int * 2)(0, 0), 2) == 0
+    L.rt_host_set_frames_in_flight(4)
+    try:
+        scene = L.create_scene(800, 600, 4000, 24, 0.9)
+        L.set_scene_camera(C.byref(scene), H.Vec3(-3, 3, -3), H.Vec3(0, 0, 0), H.Vec3(0, 1, 0), 60.0)
+        L.set_scene_light(C.byref(scene), H.Vec3(1, 1, -1), H.Vec3(1.4, 1.4, 1.4))
+        loaded = []
+        for n in ("drone", "treasure", "ground"):
+            m = L.create_mesh(os.path.join(H.ASSETS, n + ".obj").encode(), os.path.join(H.ASSETS, n + ".webp").encode())
+            loaded.append(m)
+            L.add_mesh_to_scene(C.byref(scene), m)
+        for frame in range(12):
+            drone, treasure = H.Transform(), H.Transform()
+            L.rt_host_demo_animation(frame, C.byref(drone), C.byref(treasure))
+            L.set_mesh_position(C.byref(scene.meshes[0]), drone.position)
+            L.set_mesh_rotation(C.byref(scene.meshes[0]), drone.rotation)
+            L.set_mesh_position(C.byref(scene.meshes[1]), treasure.position)
+            L.set_mesh_rotation(C.byref(scene.meshes[1]), treasure.rotation)
+            L.render_scene(C.byref(scene))
+            assert L.rt_host_last_status(C.byref(scene)) == 0
+            L.next_frame(C.byref(scene))
+        assert L.rt_host_wait(C.byref(scene)) == 0
+        assert (scene.width, scene.height) == (hashes["width"], hashes["height"])
+        for frame in range(12):
+            assert hashlib.sha256(H.frame_array(scene, frame).tobytes()).hexdigest() == hashes["frames"][frame], f"frame {frame}"
+        for m in loaded:
+            L.destroy_mesh(C.byref(m))
+        L.destroy_scene(C.byref(scene))
+    finally:
+        L.rt_host_set_frames_in_flight(1)
+        L.rt_host_set_gpus(None, 0)
