@@ -314,7 +314,10 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * over them -- 0 never, 1 when the launch has fewer than 100 000 tiles (default), 2 always),
  * "frames_in_flight" (1..8, default 1: see rt_render_frame_host), "keep_hierarchy" (rt_render_frame_instanced:
  * 1, default = the hierarchy over the instances is kept between calls and patched while few instances change
- * their place; 0 = built anew for every call).
+ * their place; 0 = built anew for every call), "instanced_wave" (rt_render_frame_instanced: 0, default = one lane per pixel walks
+ * hierarchy, instance and triangles as nested loops; 1..8 = every lane is a state machine and the wave executes the step most of
+ * its lanes wait for, lanes taking new pixels from a strip of that many tiles -- more lanes busy per instruction, more
+ * instructions: measured slower, kept for comparison).
  * Every setting produces the same image.  Read-only: "n_variants", "default_variant".
  * Unknown names give RT_ERR_INVALID. */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);

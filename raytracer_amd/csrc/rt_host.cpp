@@ -124,6 +124,7 @@ struct rt_ctx {
     std::vector<InstanceCache> inst_cache;
     StandingTlas standing;         // rt_render_frame_instanced: the hierarchy over the instances, kept between calls
     int keep_hierarchy = 1;
+    int instanced_wave = 0;        // rt_render_frame_instanced: 0 = one lane per pixel, nested loops (faster); 1..8 = the per-wavefront scheduler, that many tiles per wave
     float inst_cache_cam[3] = {0, 0, 0}, inst_cache_light[3] = {0, 0, 0};
     float build_ms = 0.0f;         // last rt_bvh_build_device
     int build_levels = 0, build_launches = 0;
@@ -979,7 +980,7 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    hipError_t le = launch_instanced(A, I, S, O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, s);
+    hipError_t le = launch_instanced(A, I, S, O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, ctx->instanced_wave, s);
     if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
     RT_HIP(ctx, hipEventRecord(ctx->inst_done[slot], s));
@@ -1240,6 +1241,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "device_build_min")) { ctx->device_build_min = value < 1 ? 1 : value; return RT_OK; }
     if (!strcmp(name, "regroup")) { ctx->regroup = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "keep_hierarchy")) { ctx->keep_hierarchy = value ? 1 : 0; ctx->standing.clear(); return RT_OK; }
+    if (!strcmp(name, "instanced_wave")) { ctx->instanced_wave = value < 0 ? 0 : (value > 8 ? 8 : value); return RT_OK; }
     if (!strcmp(name, "frames_in_flight")) {
         if (value < 1 || value > kRingSlots) return fail(ctx, RT_ERR_INVALID, "frames_in_flight must be 1..8");
         const int st = rt_sync(ctx, nullptr);            // the ring is empty whenever its length changes
@@ -1272,6 +1274,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "regroup")) { *value = ctx->regroup; return RT_OK; }
     if (!strcmp(name, "frames_in_flight")) { *value = ctx->frames_in_flight; return RT_OK; }
     if (!strcmp(name, "keep_hierarchy")) { *value = ctx->keep_hierarchy; return RT_OK; }
+    if (!strcmp(name, "instanced_wave")) { *value = ctx->instanced_wave; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
     if (!strcmp(name, "batch_rows")) { *value = ctx->batch_rows; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }

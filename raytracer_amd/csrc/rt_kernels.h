@@ -56,8 +56,9 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
 // Enqueues one frame of an instanced scene.  I.inst holds one MeshArgs per instance (pair ranges inside
 // S.pairs, live tris/attrs/texels), I.tlas / I.order the hierarchy over the non-empty ones, its depth at
 // most kTlasStackDepth - 2.  O.hit_id receives the instance index, hit_tri (optional) the triangle.
+// wave_tiles > 0 (and no work counting): the per-wavefront scheduler of rt_instanced_wave.h, a wave per strip of that many tiles.
 hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const SceneArgs& S, const OutputPlanes& O, int32_t* hit_tri,
-                            int tlas_entries, int block, hipStream_t stream);
+                            int tlas_entries, int block, int wave_tiles, hipStream_t stream);
 
 // Enqueues the bicubic upscale of n_frames RGB8 frames (width x height, frame f at rgb + f*frame_stride
 // bytes) to ARGB32 frames (scaled_width x scaled_height, frame f at argb + f*out_stride pixels).

@@ -25,23 +25,11 @@
 #include "rt_kernels.h"
 #include "rt_pixel.h"
 #include "rt_instanced.h"
+#include "rt_lds_stack.h"
+#include "rt_instanced_wave.h"
 #include "rt_sampled.h"
 
 namespace rt {
-
-// Per-lane traversal stack in LDS, laid out [entry][thread] so that the 64 lanes of a wave
-// touch 64 consecutive dwords on every push/pop (no bank conflicts).
-template <int BLOCK>
-struct LdsStack {
-    uint32_t* base;      // &stack_area[threadIdx.x]
-    uint32_t* top;       // next free entry: base + entries * BLOCK
-    __device__ __forceinline__ void init(uint32_t* b) { base = b; top = b; }
-    __device__ __forceinline__ void clear() { top = base; }
-    __device__ __forceinline__ bool empty() const { return top == base; }
-    __device__ __forceinline__ void push(uint32_t v) { *top = v; top += BLOCK; }
-    __device__ __forceinline__ void push_if(bool c, uint32_t v) { if (c) *top = v; top += c ? BLOCK : 0; }
-    __device__ __forceinline__ uint32_t pop() { top -= BLOCK; return *top; }
-};
 
 // PairNodes staged in LDS.
 struct LdsNodes {
@@ -305,13 +293,105 @@ __global__ void __launch_bounds__(BLOCK) render_instanced(const FrameArgs A, con
     if (COUNT) flush_counters(O.counters, tot);
 }
 
+// ------------------------------------------------------------------------------------------
+// Instanced scenes, scheduled per wavefront (rt_instanced_wave.h).  One wave per workgroup; a wave owns TILES
+// consecutive 8x8 tiles and keeps its 64 lanes supplied with their pixels.  Each round the wave counts its lanes
+// by state and executes the step most of them wait for; box steps, which dominate, run in short bursts.
+// ------------------------------------------------------------------------------------------
+template <int TILES>
+__global__ void __launch_bounds__(64) render_instanced_wave(const FrameArgs A, const InstancedArgs I, const SceneArgs S, const OutputPlanes O,
+                                                            int32_t* __restrict__ hit_tri, const int n_tiles) {
+    extern __shared__ uint32_t lds_stacks[];                     // entries x 64 words: one stack per lane for both levels
+    const int lane = threadIdx.x;
+    const int tiles_x = (A.width + 7) >> 3;
+    const int first_tile = blockIdx.x * TILES;
+    const int n_pix = (n_tiles - first_tile < TILES ? n_tiles - first_tile : TILES) * 64;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    WaveLane<64> L;
+    L.stack.init(&lds_stacks[lane]);
+    L.pixel = -1; L.ref = kRefEnd; L.shadow_mode = true; L.in_inst = false; L.who = -2;
+    int next = 0;                                                // wave-uniform: first pixel of the strip not handed out yet
+
+    // Hands the lanes in `want` their next pixels.  A pixel outside the frame (ragged right / bottom tiles) becomes a
+    // pixel that is already through (who = -2): its lane asks again in the next store step.
+    auto refill = [&](bool want) {
+        const unsigned long long votes = __ballot(want);
+        const int idx = next + __popcll(votes & below);
+        next += __popcll(votes);
+        if (!want) return;
+        if (idx >= n_pix) { L.pixel = -1; return; }
+        L.pixel = idx;
+        tile_pixel(first_tile + (idx >> 6), idx & 63, tiles_x, L.px, L.py);
+        if (L.px < A.width && L.py < A.height) start_pixel(L, A, I);
+        else { L.shadow_mode = true; L.ref = kRefEnd; L.who = -2; }
+    };
+    refill(true);
+
+    for (;;) {
+        const int st = lane_state(L);
+        const int n_box = __popcll(__ballot(st == W_BOX)), n_leaf = __popcll(__ballot(st == W_LEAF));
+        const int n_switch = __popcll(__ballot(st == W_SWITCH)), n_shade = __popcll(__ballot(st == W_SHADE));
+        const int n_store = __popcll(__ballot(st == W_STORE));
+        if (n_box + n_leaf + n_switch + n_shade + n_store == 0) break;          // every lane is done: the strip is rendered
+        int others = n_leaf > n_switch ? n_leaf : n_switch;
+        others = others > n_shade ? others : n_shade;
+        others = others > n_store ? others : n_store;
+        if (n_box >= others) {
+            // a burst of box steps: while at least as many lanes want one as want anything else
+            for (int burst = 0; burst < 4; burst++) {
+                const bool mine = L.pixel >= 0 && !(L.ref & kLeafBit);
+                if ((int)__popcll(__ballot(mine)) < (others > 1 ? others : 1)) break;
+                if (mine) step_box(L);
+            }
+        } else if (n_leaf == others) {
+            if (st == W_LEAF) {
+                step_leaf(L);
+                if (L.dark) L.ref = kRefEnd;                      // a blocked shadow ray is through
+            }
+        } else if (n_switch == others) {
+            if (st == W_SWITCH) step_switch(L, I, S);
+        } else if (n_shade == others) {
+            if (st == W_SHADE) step_shade(L, A, I);
+        } else {
+            const bool mine = st == W_STORE;
+            if (mine && L.who != -2) {
+                const size_t p = (size_t)L.py * (size_t)A.width + (size_t)L.px;
+                uint8_t* rgb = O.rgb + p * 3;
+                if (L.who < 0) {
+                    rgb[0] = rgb[1] = rgb[2] = 50;                                               // scene.c:156
+                } else {
+                    const F3 c = scale(L.color, L.dark ? 0.2f : L.lit);                          // scene.c:115,148-149
+                    rgb[0] = (uint8_t)(fminf(c.x * 255.0f, 255.0f));                             // scene.c:152-154 (truncation)
+                    rgb[1] = (uint8_t)(fminf(c.y * 255.0f, 255.0f));
+                    rgb[2] = (uint8_t)(fminf(c.z * 255.0f, 255.0f));
+                }
+                if (O.hit_id) O.hit_id[p] = L.who < 0 ? -1 : L.who;
+                if (hit_tri) hit_tri[p] = L.who < 0 ? -1 : (int32_t)L.btri;
+                if (O.hit_t) O.hit_t[p] = L.closest;
+                if (O.shadow) O.shadow[p] = L.who < 0 ? 255 : (L.dark ? 1 : 0);
+            }
+            refill(mine);
+        }
+    }
+}
+
 hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const SceneArgs& S, const OutputPlanes& O, int32_t* hit_tri,
-                            int tlas_entries, int block, hipStream_t stream) {
+                            int tlas_entries, int block, int wave_tiles, hipStream_t stream) {
     if (A.width <= 0 || A.height <= 0 || !O.rgb || I.n_inst < 0 || (I.n_inst > 0 && (!I.inst || !I.order))) return hipErrorInvalidValue;
     if (tlas_entries < 2 || tlas_entries > kTlasStackDepth || S.stack_entries < 2 || S.stack_entries > (uint32_t)kStackDepth) return hipErrorInvalidValue;
     const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
     if (count && !O.counters) return hipErrorInvalidValue;
     const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
+    if (wave_tiles > 0 && !count) {
+        // one stack for both levels: the hierarchy's entries, the end mark, what is left of a leaf of several instances, the
+        // mark below an instance's nodes, the instance's entries
+        const size_t wlds = (size_t)(tlas_entries + (int)S.stack_entries + 3) * 64 * sizeof(uint32_t);
+        if (wave_tiles >= 8) hipLaunchKernelGGL((render_instanced_wave<8>), dim3((tiles + 7) / 8), dim3(64), wlds, stream, A, I, S, O, hit_tri, tiles);
+        else if (wave_tiles >= 4) hipLaunchKernelGGL((render_instanced_wave<4>), dim3((tiles + 3) / 4), dim3(64), wlds, stream, A, I, S, O, hit_tri, tiles);
+        else if (wave_tiles >= 2) hipLaunchKernelGGL((render_instanced_wave<2>), dim3((tiles + 1) / 2), dim3(64), wlds, stream, A, I, S, O, hit_tri, tiles);
+        else hipLaunchKernelGGL((render_instanced_wave<1>), dim3(tiles), dim3(64), wlds, stream, A, I, S, O, hit_tri, tiles);
+        return hipGetLastError();
+    }
     const int threads = block == 256 ? 256 : 64;
     const size_t lds = (size_t)(tlas_entries + (int)S.stack_entries) * (size_t)threads * sizeof(uint32_t);
     if (block == 256) {

@@ -26,6 +26,7 @@ def main():
     p.add_argument("--spacing", type=float, default=1.05)
     p.add_argument("--frames", default="0,45")
     p.add_argument("--reps", type=int, default=5)
+    p.add_argument("--wave", type=int, default=-1, help="option instanced_wave: tiles per wave of the per-wavefront scheduler, 0 = nested loops per lane")
     p.add_argument("--no-rebuild", action="store_true", help="move the drone by its transform only (no per-frame BVH rebuild)")
     a = p.parse_args()
     from raytracer_amd import capi, demo
@@ -33,6 +34,8 @@ def main():
     torch.cuda.set_device(0)
     scene = demo.DemoScene(0)
     ctx = scene.ctx
+    if a.wave >= 0:
+        ctx.set_option("instanced_wave", a.wave)
     rng = np.random.default_rng(3)
     ids, tfs = [0, 2], [None, capi.Transform()]
     half = (a.side - 1) / 2.0
@@ -92,7 +95,7 @@ def main():
            "config": {"workload": f"{W}x{H}, {len(ids)} instances ({placed} placed triangles): {a.side}x{a.side} treasures + ground + drone, "
                                   "hierarchy over the instances rebuilt on the host per frame"
                                   + ("" if a.no_rebuild else "; the drone's vertices rewritten, its BVH rebuilt and re-uploaded per frame")},
-           "dtype": "f32", "frames": rows}
+           "dtype": "f32", "instanced_wave": ctx.get_option("instanced_wave"), "frames": rows}
     print(json.dumps(out), flush=True)
     scene.close()
 

@@ -60,6 +60,7 @@ def main():
     p.add_argument("--batch", type=int, default=0, help="> 0: rt_render_frames with this many consecutive frames per launch")
     p.add_argument("--mode", default="frames", choices=["frames", "bench", "sampled", "instanced", "upscale"],
                    help="bench: the launches of bench.py's timed region (96 steps, 8 frames per launch); sampled: 4K/16 samples/2 lights; instanced: 56x56 treasures; upscale: 16 frames 1080p -> scale 0.9")
+    p.add_argument("--wave", type=int, default=-1, help="option instanced_wave (instanced mode)")
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     a = p.parse_args()
@@ -71,6 +72,8 @@ def main():
     if a.block:
         scene.ctx.set_option("block", a.block)
     scene.ctx.set_option("timing", 0)
+    if a.wave >= 0:
+        scene.ctx.set_option("instanced_wave", a.wave)
     if a.mode == "bench":
         import bench
         seq = bench.frame_sequence(list(range(demo.N_FRAMES)), 96)

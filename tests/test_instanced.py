@@ -384,3 +384,25 @@ def test_gpu_successive_calls_with_partly_changed_lists(gscene, po, meshes):
         fr, inst_want, _ = oracle_planes(po, meshes, s_ids, s_tfs, po.default_camera(), l, w, h)
         assert np.array_equal(hi.cpu().numpy(), inst_want)
         assert np.array_equal(rgb.cpu().numpy(), fr.rgb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiles", [1, 4])
+def test_gpu_wave_scheduled_kernel_equals_reference_loop(gscene, po, meshes, tiles):
+    """Option "instanced_wave": the per-wavefront scheduler (every lane a state machine, lanes refilled from a strip of
+    tiles) gives the planes of the reference loop -- grids of instances at ragged sizes, coincident instances (the earlier
+    list entry wins an equal distance), and the reference scene's full-size hashes."""
+    gscene.set_option("instanced_wave", tiles)
+    try:
+        for n_side, size in ((1, (240, 135)), (5, (333, 211)), (10, (161, 93))):
+            ids, tfs = grid_scene(po, n_side, seed=n_side)
+            fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), *size)
+            check(gpu_render(gscene, po, ids, tfs, *size), fr, inst, tri)
+        t = po.animation_transforms(7)
+        ids, tfs = [1, 0, 1, 2, 1], [t[1], t[0], t[1], t[2], t[1]]                    # the treasure three times in one place
+        fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), 200, 120)
+        got = gpu_render(gscene, po, ids, tfs, 200, 120)
+        check(got, fr, inst, tri)
+        assert 0 in inst and 2 not in inst and 4 not in inst
+    finally:
+        gscene.set_option("instanced_wave", 0)
