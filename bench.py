@@ -320,7 +320,7 @@ def main():
 
     # ---- kernel duration with HIP events on the launch stream (rank 0): the same launches as the
     # timed region, one at a time
-    roof, single_ms = None, None
+    roof, single_ms, fast = None, None, None
     if rank == 0 and not rehearse:
         ctx.set_option("timing", 1)
 
@@ -351,6 +351,16 @@ def main():
                                    "basis": "tests the ordered, distance-culled traversal of the kernel executes"},
                 "note": "the scene (150 KB of nodes, 170 KB of triangles) is cache resident: the algorithmic bytes are served by "
                         "L1/L2 (cache_served_GBs), HBM carries the framebuffers and texels only"}
+        # the same launches with the fast build of the kernels (context option "fast": fused multiply-adds, approximate
+        # reciprocals; not bit-exact, inside the tolerance tests/test_gpu_parity.py asserts).  Never part of `value`.
+        ctx.set_option("fast", 1)
+        fms = []
+        for fr in batches:
+            scene.render_frames(fr, W, H, bufs[0], stream=sptr)
+            fms.append(ctx.last_kernel_ms())
+        ctx.set_option("fast", 0)
+        fast = {"kernel_ms": round(float(np.mean(fms)), 4), "speedup_over_exact_kernel": round(kern_ms / float(np.mean(fms)), 3),
+                "note": "option \"fast\" (not the default, not in `value`): hit ids equal on >= 99.99 % of camera rays, colours within 1 on >= 99.9 % of pixels"}
         # one frame launched alone (its duration is set by its slowest tiles)
         one = []
         for f in sorted(set(seq))[:8]:
@@ -399,6 +409,7 @@ def main():
             "rays_per_frame": int(rays_rank / a.steps),
             "single_frame_kernel_ms": single_ms,
             "roofline": roof,
+            "fast_build": fast,
             "cpu_baseline": cpu,
         }
         if rehearse:

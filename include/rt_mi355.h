@@ -314,11 +314,16 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * over them -- 0 never, 1 when the launch has fewer than 100 000 tiles (default), 2 always),
  * "frames_in_flight" (1..8, default 1: see rt_render_frame_host), "keep_hierarchy" (rt_render_frame_instanced:
  * 1, default = the hierarchy over the instances is kept between calls and patched while few instances change
- * their place; 0 = built anew for every call), "instanced_wave" (rt_render_frame_instanced: 0, default = one lane per pixel walks
+ * their place; 0 = built anew for every call), "fast" (0, default = the exact build of the kernels: every float
+ * operation of the reference once, in its order, no fused multiply-adds, correctly rounded division and square root --
+ * all outputs bit-identical to the reference; 1 = the fast build for rt_render_frame, rt_render_frame_strips and
+ * rt_render_frames: contraction on, hardware reciprocal / reciprocal square root, the slab test as one fused multiply-add per
+ * bound.  Not bit-exact: hit ids equal on at least 99.99 % of camera rays and 8-bit colours within 1 on at least 99.9 % of
+ * pixels against the exact build, which the GPU tests assert; measured about 6 % faster), "instanced_wave" (rt_render_frame_instanced: 0, default = one lane per pixel walks
  * hierarchy, instance and triangles as nested loops; 1..8 = every lane is a state machine and the wave executes the step most of
  * its lanes wait for, lanes taking new pixels from a strip of that many tiles -- more lanes busy per instruction, more
  * instructions: measured slower, kept for comparison).
- * Every setting produces the same image.  Read-only: "n_variants", "default_variant".
+ * Every setting except "fast" produces the same image.  Read-only: "n_variants", "default_variant".
  * Unknown names give RT_ERR_INVALID. */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);
 int rt_get_option(const rt_ctx* ctx, const char* name, int* value);

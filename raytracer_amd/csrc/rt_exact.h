@@ -28,10 +28,20 @@ RT_HD float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }       
 RT_HD F3 cross(F3 a, F3 b) {                                                        // vec3.c:23
     return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// Reciprocal and reciprocal square root.  Exact build: the correctly rounded division (and square root) the reference's
+// expressions ask for.  Fast build of the kernels (RT_FAST, device code only): the hardware approximations, one
+// instruction each, about 1 ulp.
+#if defined(RT_FAST) && defined(__HIP_DEVICE_COMPILE__)
+RT_HD float rcp1(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_HD float rsqrt1(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+RT_HD float rcp1(float x) { return 1.0f / x; }
+RT_HD float rsqrt1(float x) { return 1.0f / sqrtf(x); }
+#endif
 // vec3.c:15,31,35: v * (1.0f / sqrtf(v.v)) -- a reciprocal and three multiplies, not three divides.
-RT_HD F3 unit(F3 a) { return scale(a, 1.0f / sqrtf(dot(a, a))); }
+RT_HD F3 unit(F3 a) { return scale(a, rsqrt1(dot(a, a))); }
 RT_HD F3 mul(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }            // vec3.c:39
-RT_HD F3 recip(F3 a) { return f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z); }             // aabb.c:34-38
+RT_HD F3 recip(F3 a) { return f3(rcp1(a.x), rcp1(a.y), rcp1(a.z)); }                // aabb.c:34-38
 
 // fminf/fmaxf as the reference's C library evaluates them where the result is stored (box bounds, aabb.c:10-23):
 // of two equal operands -- +0 and -0 -- the second is returned, and a NaN second operand is ignored.
@@ -70,7 +80,7 @@ RT_HD bool moller_trumbore(F3 o, F3 d, F3 v0, F3 e1, F3 e2, float& t, float& u, 
     F3 h = cross(d, e2);
     float a = dot(e1, h);
     if (a > -eps && a < eps) return false;
-    float f = 1.0f / a;
+    float f = rcp1(a);
     F3 s = sub(o, v0);
     u = f * dot(s, h);
     if (u < 0.0f || u > 1.0f) return false;

@@ -16,6 +16,11 @@
 
 using namespace rt;
 
+// the fast build of the kernels (rt_kernels_fast.hip)
+extern "C" hipError_t rt_fast_launch_render(const void* frame_args, const void* scene_args, const void* planes, const void* launch_config, hipStream_t stream);
+extern "C" hipError_t rt_fast_launch_batch(const void* d_frames, int n_frames, int width, int height, const void* scene_args, uint8_t* rgb,
+                                           size_t frame_stride, int first_row, int chunk, int swizzle, int block, hipStream_t stream);
+
 namespace {
 
 constexpr int kBatchSlots = 4;
@@ -124,6 +129,7 @@ struct rt_ctx {
     std::vector<InstanceCache> inst_cache;
     StandingTlas standing;         // rt_render_frame_instanced: the hierarchy over the instances, kept between calls
     int keep_hierarchy = 1;
+    int fast = 0;                  // 1: rt_render_frame / rt_render_frames / strips run the fast build of the kernels (not bit-exact)
     int instanced_wave = 0;        // rt_render_frame_instanced: 0 = one lane per pixel, nested loops (faster); 1..8 = the per-wavefront scheduler, that many tiles per wave
     float inst_cache_cam[3] = {0, 0, 0}, inst_cache_light[3] = {0, 0, 0};
     float build_ms = 0.0f;         // last rt_bvh_build_device
@@ -686,7 +692,7 @@ int render_frame_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* ligh
         cfg.parity = (int)(ctx->two_pass_frames++ & 1u);
         A.defer_budget = ctx->budget;
     }
-    hipError_t le = launch_render(A, S, O, cfg, s);
+    hipError_t le = ctx->fast ? rt_fast_launch_render(&A, &S, &O, &cfg, s) : launch_render(A, S, O, cfg, s);
     if (le != hipSuccess) {
         // leave the work-distribution words of the persistent / two-pass variants in their idle state
         (void)hipDeviceSynchronize();
@@ -792,7 +798,8 @@ int render_frames_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* lig
     } else {
         RT_HIP(ctx, hipMemcpyAsync(d, h, (size_t)n_frames * sizeof(FrameArgs), hipMemcpyHostToDevice, s));
         if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-        le = launch_batch(d, n_frames, width, height, S, (uint8_t*)d_rgb, frame_stride, first_row, chunk, ctx->xcd_swizzle, ctx->cfg.block, s);
+        le = ctx->fast ? rt_fast_launch_batch(d, n_frames, width, height, &S, (uint8_t*)d_rgb, frame_stride, first_row, chunk, ctx->xcd_swizzle, ctx->cfg.block, s)
+                       : launch_batch(d, n_frames, width, height, S, (uint8_t*)d_rgb, frame_stride, first_row, chunk, ctx->xcd_swizzle, ctx->cfg.block, s);
     }
     if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
@@ -1241,6 +1248,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "device_build_min")) { ctx->device_build_min = value < 1 ? 1 : value; return RT_OK; }
     if (!strcmp(name, "regroup")) { ctx->regroup = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "keep_hierarchy")) { ctx->keep_hierarchy = value ? 1 : 0; ctx->standing.clear(); return RT_OK; }
+    if (!strcmp(name, "fast")) { ctx->fast = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "instanced_wave")) { ctx->instanced_wave = value < 0 ? 0 : (value > 8 ? 8 : value); return RT_OK; }
     if (!strcmp(name, "frames_in_flight")) {
         if (value < 1 || value > kRingSlots) return fail(ctx, RT_ERR_INVALID, "frames_in_flight must be 1..8");
@@ -1275,6 +1283,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "frames_in_flight")) { *value = ctx->frames_in_flight; return RT_OK; }
     if (!strcmp(name, "keep_hierarchy")) { *value = ctx->keep_hierarchy; return RT_OK; }
     if (!strcmp(name, "instanced_wave")) { *value = ctx->instanced_wave; return RT_OK; }
+    if (!strcmp(name, "fast")) { *value = ctx->fast; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
     if (!strcmp(name, "batch_rows")) { *value = ctx->batch_rows; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }

@@ -548,6 +548,7 @@ hipError_t launch_batch(const FrameArgs* d_frames, int n_frames, int width, int 
     return launch_batch_t<256, kStackDepth>(d_frames, n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, stream);
 }
 
+#if !defined(RT_FAST)
 // ------------------------------------------------------------------------------------------
 // Batched frames for callers that cannot allocate (rt_render_frames_noalloc): the per-frame constants
 // that rt_render_frames stages in a device array of the context go through this file-scope array
@@ -597,6 +598,8 @@ hipError_t launch_batch_noalloc(int device, const FrameArgs* h_frames, int n_fra
     if (e != hipSuccess) return e;
     return launch_batch(static_cast<const FrameArgs*>(ptr), n_frames, width, height, S, rgb, frame_stride, first_row, chunk, swizzle, block, stream);
 }
+
+#endif  // !RT_FAST
 
 // ------------------------------------------------------------------------------------------
 // Variant 3: tiles, with cooperative groups where rays are long.
@@ -1059,3 +1062,19 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
 }
 
 }  // namespace rt
+
+#if defined(RT_FAST)
+// The fast build of this file (rt_kernels_fast.hip: fused multiply-adds, approximate division and square root, the
+// slab test above; `rt` is renamed for the whole translation unit) is reached through these two entry points.  The
+// argument structures are the ones of the exact build, layout for layout.
+extern "C" hipError_t rt_fast_launch_render(const void* frame_args, const void* scene_args, const void* planes, const void* launch_config,
+                                            hipStream_t stream) {
+    return rt::launch_render(*static_cast<const rt::FrameArgs*>(frame_args), *static_cast<const rt::SceneArgs*>(scene_args),
+                             *static_cast<const rt::OutputPlanes*>(planes), *static_cast<const rt::LaunchConfig*>(launch_config), stream);
+}
+extern "C" hipError_t rt_fast_launch_batch(const void* d_frames, int n_frames, int width, int height, const void* scene_args, uint8_t* rgb,
+                                           size_t frame_stride, int first_row, int chunk, int swizzle, int block, hipStream_t stream) {
+    return rt::launch_batch(static_cast<const rt::FrameArgs*>(d_frames), n_frames, width, height, *static_cast<const rt::SceneArgs*>(scene_args), rgb,
+                            frame_stride, first_row, chunk, swizzle, block, stream);
+}
+#endif

@@ -69,6 +69,24 @@ constexpr uint32_t kLeafBatch = 2;       // triangles fetched together in a leaf
 // (lmax.y,lmax.z) and the same for the right box -- against matching pairs of the ray's origin and
 // reciprocal direction.
 typedef float v2f __attribute__((ext_vector_type(2)));
+#if defined(RT_FAST)
+// Fast build (not bit-exact): (bound - o) * inv becomes bound * inv - o * inv with o * inv computed once per ray and
+// mesh, one packed fused multiply-add per pair of bounds.  Where a direction component is zero (inv = inf) the
+// products turn into NaNs that fminf/fmaxf drop, which only ever lets MORE boxes through than the exact form.
+struct SlabRay {
+    v2f ixy, izx, iyz, pxy, pzx, pyz;            // reciprocal direction pairs, origin * reciprocal direction pairs
+};
+RT_HD SlabRay slab_ray(F3 o, F3 inv) {
+    SlabRay r;
+    r.ixy = v2f{inv.x, inv.y}; r.izx = v2f{inv.z, inv.x}; r.iyz = v2f{inv.y, inv.z};
+    r.pxy = v2f{o.x, o.y} * r.ixy; r.pzx = v2f{o.z, o.x} * r.izx; r.pyz = v2f{o.y, o.z} * r.iyz;
+    return r;
+}
+RT_HD bool slab_half(v2f p0, v2f p1, v2f p2, const SlabRay& r, float& entry) {
+    const v2f a0 = p0 * r.ixy - r.pxy;          // min.x, min.y
+    const v2f a1 = p1 * r.izx - r.pzx;          // min.z, max.x
+    const v2f a2 = p2 * r.iyz - r.pyz;          // max.y, max.z
+#else
 struct SlabRay {
     v2f oxy, ozx, oyz, ixy, izx, iyz;
 };
@@ -82,6 +100,7 @@ RT_HD bool slab_half(v2f p0, v2f p1, v2f p2, const SlabRay& r, float& entry) {
     const v2f a0 = (p0 - r.oxy) * r.ixy;        // min.x, min.y
     const v2f a1 = (p1 - r.ozx) * r.izx;        // min.z, max.x
     const v2f a2 = (p2 - r.oyz) * r.iyz;        // max.y, max.z
+#endif
     float tmin = fminf(a0.x, a1.y), tmax = fmaxf(a0.x, a1.y);
     tmin = fmaxf(tmin, fminf(a0.y, a2.x)); tmax = fminf(tmax, fmaxf(a0.y, a2.x));
     tmin = fmaxf(tmin, fminf(a1.x, a2.y)); tmax = fminf(tmax, fmaxf(a1.x, a2.y));

@@ -474,3 +474,46 @@ def test_whole_animation_equals_the_compiled_reference(capi, ctx, po):
             assert hashlib.sha256(got[k].tobytes()).hexdigest() == gold["frames"][f], f
             total.update(got[k].tobytes())
     assert total.hexdigest() == gold["all_frames_sha256"]
+
+
+def test_fast_build_stays_inside_the_stated_tolerance(golden_frames, golden_hashes):
+    """Context option "fast": the kernels built with fused multiply-adds and approximate reciprocals.  Against the golden
+    planes of the compiled reference (240x135) and against the exact build at 1920x1080: the same hit id on at least
+    99.99 % of camera rays, 8-bit colours within 1 on at least 99.9 % of pixels -- and the exact build, which stays the
+    default, still gives the golden hashes afterwards."""
+    import hashlib
+    import torch
+    from raytracer_amd import demo
+    scene = demo.DemoScene(0)
+    try:
+        ctx = scene.ctx
+        assert ctx.get_option("fast") == 0
+
+        def render(frame, w, h, batched=False):
+            rgb = torch.empty((1, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            hid = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+            scene.render(frame, w, h, rgb[0], hit_id=hid)
+            if batched:
+                scene.render_frames([frame], w, h, rgb)
+            ctx.sync()
+            return rgb[0].cpu().numpy(), hid.cpu().numpy()
+
+        def close_enough(rgb, hid, want_rgb, want_hid, what):
+            same = float((hid == want_hid).mean())
+            within = float((np.abs(rgb.astype(np.int16) - want_rgb.astype(np.int16)).max(axis=2) <= 1).mean())
+            assert same >= 0.9999, f"{what}: hit ids equal on {same:.6f} of camera rays"
+            assert within >= 0.999, f"{what}: colours within 1 on {within:.6f} of pixels"
+
+        ctx.set_option("fast", 1)
+        for f in (0, 45, 95):
+            rgb, hid = render(f, 240, 135, batched=True)
+            close_enough(rgb, hid, golden_frames[f"f{f}_rgb"], golden_frames[f"f{f}_hit_id"], f"240x135 frame {f}")
+        fast_full = {f: render(f, 1920, 1080, batched=True) for f in (0, 45)}
+        ctx.set_option("fast", 0)
+        for f in (0, 45):
+            rgb, hid = render(f, 1920, 1080, batched=True)
+            assert hashlib.sha256(rgb.tobytes()).hexdigest() == golden_hashes["frames"][f"1920x1080_f{f}"]["rgb"]
+            assert hashlib.sha256(hid.tobytes()).hexdigest() == golden_hashes["frames"][f"1920x1080_f{f}"]["hit_id"]
+            close_enough(fast_full[f][0], fast_full[f][1], rgb, hid, f"1920x1080 frame {f}")
+    finally:
+        scene.close()
