@@ -129,6 +129,7 @@ struct rt_ctx {
     std::vector<InstanceCache> inst_cache;
     StandingTlas standing;         // rt_render_frame_instanced: the hierarchy over the instances, kept between calls
     int keep_hierarchy = 1;
+    int screen_cull = 1;           // meshes are skipped for camera rays of tiles their root box cannot reach (mesh_screen_rect)
     int fast = 0;                  // 1: rt_render_frame / rt_render_frames / strips run the fast build of the kernels (not bit-exact)
     int instanced_wave = 0;        // rt_render_frame_instanced: 0 = one lane per pixel, nested loops (faster); 1..8 = the per-wavefront scheduler, that many tiles per wave
     float inst_cache_cam[3] = {0, 0, 0}, inst_cache_light[3] = {0, 0, 0};
@@ -306,6 +307,8 @@ void fill_frame(const rt_ctx* ctx, const rt_camera& camera, const rt_light& ligh
     for (int32_t m = 0; m < n_transforms; m++) {
         A.mesh[m] = ctx->meshes[(size_t)m].proto;
         fill_placement(transforms[m], A, A.mesh[m]);
+        if (ctx->screen_cull) mesh_screen_rect(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max, A, A.vis[m]);
+        else { A.vis[m][0] = 0; A.vis[m][1] = 0; A.vis[m][2] = (width + 7) / 8; A.vis[m][3] = (height + 7) / 8; }
     }
 }
 
@@ -1249,6 +1252,7 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "regroup")) { ctx->regroup = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "keep_hierarchy")) { ctx->keep_hierarchy = value ? 1 : 0; ctx->standing.clear(); return RT_OK; }
     if (!strcmp(name, "fast")) { ctx->fast = value ? 1 : 0; return RT_OK; }
+    if (!strcmp(name, "screen_cull")) { ctx->screen_cull = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "instanced_wave")) { ctx->instanced_wave = value < 0 ? 0 : (value > 8 ? 8 : value); return RT_OK; }
     if (!strcmp(name, "frames_in_flight")) {
         if (value < 1 || value > kRingSlots) return fail(ctx, RT_ERR_INVALID, "frames_in_flight must be 1..8");
@@ -1284,6 +1288,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "keep_hierarchy")) { *value = ctx->keep_hierarchy; return RT_OK; }
     if (!strcmp(name, "instanced_wave")) { *value = ctx->instanced_wave; return RT_OK; }
     if (!strcmp(name, "fast")) { *value = ctx->fast; return RT_OK; }
+    if (!strcmp(name, "screen_cull")) { *value = ctx->screen_cull; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }
     if (!strcmp(name, "batch_rows")) { *value = ctx->batch_rows; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }

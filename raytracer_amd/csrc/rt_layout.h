@@ -111,6 +111,10 @@ struct FrameArgs {
     // Two-pass variant: node visits one lane may spend on a pixel before handing it to the
     // cooperative pass.
     int32_t defer_budget;
+    // Per mesh, the 8x8-pixel tiles of the FRAME {x0, y0, x1, y1} (half open) outside of which no camera ray can pass the
+    // mesh's root box, not even with the rounding of the float test (see mesh_screen_rect, rt_pack.h): there the
+    // reference's root test (bvh.c:82) fails for certain, and the mesh is skipped without transforming the ray.
+    int32_t vis[kMaxMeshes][4];
     MeshArgs mesh[kMaxMeshes];
 };
 

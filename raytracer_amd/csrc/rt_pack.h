@@ -475,6 +475,54 @@ inline bool coop_rect(const WorldBox& b, const double scene_lo[3], const double 
 }
 
 
+// Tiles (8x8 pixels, {x0, y0, x1, y1} half open) outside of which a camera ray of the frame cannot pass the root box of a
+// mesh placed by tf -- with certainty, i.e. including what float rounding can do to the reference's test in mesh space
+// (ray.c:5-22 + aabb.c:33-56).  That test works on values whose absolute errors are a few units in the last place of
+// the magnitudes involved (camera position, placement, box coordinates; the translation and the camera position cancel in
+// mesh space), so a ray it accepts passes, in exact arithmetic, within `slack` of the box, where slack is taken as 2^-18 of
+// the sum of those magnitudes (64 units in the last place).  The box corners are projected in double precision; the slack,
+// seen from the nearest corner, an angular allowance of 2^-14 for the rounding of the ray direction itself, and two
+// pixels (sample jitter, tile rounding) are added on every side.  A corner at or behind the camera plane, or a frame so
+// narrow that the allowance exceeds it, gives the whole frame.
+inline void mesh_screen_rect(const rt_transform& tf, const float* bmin, const float* bmax, const FrameArgs& A, int32_t rect[4]) {
+    const int tiles_x = (A.width + 7) / 8, tiles_y = (A.full_height + 7) / 8;
+    rect[0] = 0; rect[1] = 0; rect[2] = tiles_x; rect[3] = tiles_y;
+    const WorldBox b = world_box(tf, bmin, bmax);
+    double mag = fabs(tf.position.x) + fabs(tf.position.y) + fabs(tf.position.z);
+    for (int i = 0; i < 3; i++) {
+        mag += fabs((double)A.cam_pos[i]);
+        const double m = fabs((double)bmin[i]) > fabs((double)bmax[i]) ? fabs((double)bmin[i]) : fabs((double)bmax[i]);
+        mag += m;
+    }
+    const double slack = mag * (1.0 / 262144.0);
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300}, z_min = 1e300, s_max = 0.0;
+    for (int c = 0; c < 8; c++) {
+        double w[3];
+        for (int i = 0; i < 3; i++) w[i] = b.corner[c][i] - (double)A.cam_pos[i];
+        const double z = w[0] * A.cam_fwd[0] + w[1] * A.cam_fwd[1] + w[2] * A.cam_fwd[2];
+        if (!(z > 1e-4) || !(z - 2.0 * slack > 0.25 * z)) return;            // behind the camera plane, or closer than the slack can tell
+        const double sx = (w[0] * A.cam_right[0] + w[1] * A.cam_right[1] + w[2] * A.cam_right[2]) / z;
+        const double sy = (w[0] * A.cam_up[0] + w[1] * A.cam_up[1] + w[2] * A.cam_up[2]) / z;
+        if (!(sx == sx) || !(sy == sy)) return;
+        lo[0] = sx < lo[0] ? sx : lo[0]; hi[0] = sx > hi[0] ? sx : hi[0];
+        lo[1] = sy < lo[1] ? sy : lo[1]; hi[1] = sy > hi[1] ? sy : hi[1];
+        z_min = z < z_min ? z : z_min;
+        const double a = fabs(sx) > fabs(sy) ? fabs(sx) : fabs(sy);
+        s_max = a > s_max ? a : s_max;
+    }
+    // moving a point by `slack` moves its projection by at most slack * (1 + |s|) / (z - slack); z - slack >= z / 2 here
+    const double allow = 2.0 * slack * (1.0 + s_max) / z_min + (1.0 + s_max * s_max) / 16384.0;
+    const double kx = 0.5 * A.width / ((double)A.aspect * A.scale), ky = 0.5 * A.full_height / (double)A.scale;
+    if (!(kx > 0) || !(ky > 0) || !(kx < 1e12) || !(ky < 1e12)) return;
+    // pixel coordinate of a projection (inverse of camera.c:18-19 and scene.c:61-62): px = (sx / (aspect*scale) + 1) / 2 * width - 1/2
+    const double px_lo = (lo[0] - allow) * kx + 0.5 * A.width - 0.5 - 2.0, px_hi = (hi[0] + allow) * kx + 0.5 * A.width - 0.5 + 2.0;
+    const double py_lo = 0.5 * A.full_height - (hi[1] + allow) * ky - 0.5 - 2.0, py_hi = 0.5 * A.full_height - (lo[1] - allow) * ky - 0.5 + 2.0;
+    auto tile_lo = [](double v, int n) { const double t = floor(v / 8.0); return t < 0 ? 0 : (t > n ? n : (int)t); };
+    auto tile_hi = [](double v, int n) { const double t = floor(v / 8.0) + 1.0; return t < 0 ? 0 : (t > n ? n : (int)t); };
+    rect[0] = tile_lo(px_lo, tiles_x); rect[1] = tile_lo(py_lo, tiles_y);
+    rect[2] = tile_hi(px_hi, tiles_x); rect[3] = tile_hi(py_hi, tiles_y);
+}
+
 // ---- hierarchy over placed instances (never used for results, only to propose instances) ----------
 // World-space box of an instance, padded so that float rounding in the world-space slab test can never
 // reject a ray that the exact test in the instance's own space would accept: 1e-4 of the box's extent

@@ -335,8 +335,11 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     float closest = 1e30f;
     int who = -1;
     Hit best = no_hit();
+    const int tile_x = px >> 3, tile_y = frame_row(A, py) >> 3;
     for (int m = 0; m < A.n_mesh; m++) {
         const MeshArgs& M = A.mesh[m];
+        // outside A.vis[m] the root test below fails for certain; counting and reference-order runs make it anyway
+        if (!COUNT && !FULL && (tile_x < A.vis[m][0] || tile_x >= A.vis[m][2] || tile_y < A.vis[m][1] || tile_y >= A.vis[m][3])) continue;
         const F3 lo = f3(M.cam_o);                                     // ray.c:19 (same for every pixel)
         const F3 ld = unit(xform_vector<4>(M.inv, wd));                // ray.c:20,22
         Hit h = no_hit();

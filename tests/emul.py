@@ -55,6 +55,8 @@ def lib():
                                      C.POINTER(C.c_uint32)]
         L.emul_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), i32, i32, i32,
                                   vp, vp, vp, vp, C.POINTER(Counters), i32, vp, vp]
+        L.emul_screen_rect.argtypes = [C.POINTER(Transform), vp, vp, C.POINTER(Camera), C.POINTER(Light), i32, i32, vp]
+        L.emul_screen_rect.restype = None
         L.emul_sample_offset.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_float)] * 2
         L.emul_sample_offset.restype = None
         L.emul_render_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, C.c_uint32,
@@ -77,6 +79,16 @@ def upscale(rgb, scaled_width, scaled_height, rows=8):
     out = np.zeros((scaled_height, scaled_width), np.uint32)
     lib().emul_upscale(rgb.ctypes.data, rgb.shape[1], rgb.shape[0], scaled_width, scaled_height, rows, out.ctypes.data)
     return out
+
+
+def screen_rect(tf, bmin, bmax, cam, light, width, height):
+    """mesh_screen_rect: tiles {x0, y0, x1, y1} outside of which camera rays cannot pass the placed box."""
+    lo = np.ascontiguousarray(bmin, np.float32)
+    hi = np.ascontiguousarray(bmax, np.float32)
+    out = np.zeros(4, np.int32)
+    t, c, l = conv(tf, Transform), conv(cam, Camera), conv(light, Light)
+    lib().emul_screen_rect(C.byref(t), lo.ctypes.data, hi.ctypes.data, C.byref(c), C.byref(l), width, height, out.ctypes.data)
+    return [int(v) for v in out]
 
 
 def conv(obj, cls):
@@ -117,7 +129,7 @@ class Scene:
         assert lib().emul_mesh_prios(self.h, mesh, out.ctypes.data) == 0
         return out
 
-    def render(self, cam, light, tfs, w, h, full=False, per_pixel=False):
+    def render(self, cam, light, tfs, w, h, full=False, per_pixel=False, screen_cull=False):
         arr = (Transform * max(len(tfs), 1))(*[conv(t, Transform) for t in tfs])
         rgb = np.zeros((h, w, 3), np.uint8)
         hid = np.zeros((h, w), np.int32)
@@ -128,7 +140,7 @@ class Scene:
         pt = np.zeros((h, w), np.uint32) if per_pixel else None
         cam2, light2 = conv(cam, Camera), conv(light, Light)
         st = lib().emul_render(self.h, C.byref(cam2), C.byref(light2), arr, len(tfs), w, h, rgb.ctypes.data,
-                               hid.ctypes.data, ht.ctypes.data, sh.ctypes.data, C.byref(cnt), 1 if full else 0,
+                               hid.ctypes.data, ht.ctypes.data, sh.ctypes.data, C.byref(cnt), 2 if screen_cull else (1 if full else 0),
                                ps.ctypes.data if per_pixel else None, pt.ctypes.data if per_pixel else None)
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_id": hid, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(), "px_slabs": ps,

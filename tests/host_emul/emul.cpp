@@ -86,6 +86,14 @@ int emul_mesh_prios(void* sp, int mesh, uint32_t* out) {
     return RT_OK;
 }
 
+// The tiles outside of which the product skips a mesh for camera rays (mesh_screen_rect).
+void emul_screen_rect(const rt_transform* tf, const float* bmin, const float* bmax, const rt_camera* cam, const rt_light* light,
+                      int32_t width, int32_t height, int32_t* rect4) {
+    FrameArgs A; memset(&A, 0, sizeof A);
+    fill_camera(*cam, *light, width, height, A);
+    mesh_screen_rect(*tf, bmin, bmax, A, rect4);
+}
+
 // Per-frame constants as the product computes them: inv rows 0..3 (16 floats) and nrm (9 floats).
 void emul_placement(const rt_transform* tf, const rt_camera* cam, const rt_light* light, float* inv16, float* nrm9,
                     float* cam_o3, float* lit_d3, uint32_t* w_mode) {
@@ -116,6 +124,7 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
         M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
         fill_placement(tfs[m], A, M);
+        mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
     }
     GlobalNodes nodes; nodes.all = s->all_pairs.data();
     unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
@@ -125,9 +134,11 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         for (int x = 0; x < width; x++) {
             ArrayStack st;
             Work w; w.slabs = 0; w.tris = 0;
-            // full: 1 = reference visiting order; 0 = nearer child first with distance culling
-            PixelOut r = full ? shade_pixel<true, true, false>(A, nodes, Solo(), x, y, st, w)
-                              : shade_pixel<true, false, false>(A, nodes, Solo(), x, y, st, w);
+            // full: 1 = reference visiting order; 0 = nearer child first with distance culling; 2 = the same without work
+            // counts, as the kernels run it: meshes are skipped for tiles outside their screen rectangle
+            PixelOut r = full == 1 ? shade_pixel<true, true, false>(A, nodes, Solo(), x, y, st, w)
+                       : full == 2 ? shade_pixel<false, false, false>(A, nodes, Solo(), x, y, st, w)
+                                   : shade_pixel<true, false, false>(A, nodes, Solo(), x, y, st, w);
             const size_t p = (size_t)y * width + x;
             rgb[p * 3] = r.r; rgb[p * 3 + 1] = r.g; rgb[p * 3 + 2] = r.b;
             if (hit_id) hit_id[p] = r.hit_id;
@@ -167,6 +178,7 @@ int emul_render_sampled(void* sp, const rt_camera* cam, const rt_light* lights, 
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
         M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
         fill_placement(tfs[m], A, M);
+        mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
     }
     SampleArgs X;
     fill_samples(lights, n_lights, spp, seed, A, X);

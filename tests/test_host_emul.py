@@ -368,3 +368,75 @@ def test_culling_keeps_the_reference_result_on_adversarial_scenes(po):
         s.close()
         n += 1
     assert n >= 20
+
+
+# ------------------------------------------------------------------------------ meshes skipped by screen rectangle
+def test_screen_rectangle_contains_every_pixel_whose_ray_passes_the_root_box(po):
+    """mesh_screen_rect promises: outside the rectangle the reference's root test (ray.c:5-22 transform, aabb.c:33-56)
+    fails.  Checked pixel by pixel with the oracle's own get_camera_ray / transform_ray / ray_aabb_intersect on boxes,
+    placements and cameras that stress it: far from the origin, camera close to the box, narrow and wide views,
+    flat boxes, a box behind or around the camera (then the rectangle must be the whole frame)."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    L = po.lib()
+    light = po.default_light()
+    w, h = 96, 54
+    culled_somewhere = 0
+    for trial in range(60):
+        off = rng.choice([0.0, 10.0, 1.0e3, 1.0e4]) * rng.normal(size=3)
+        half = 10 ** rng.uniform(-1.5, 0.7, size=3)
+        if trial % 5 == 0:
+            half[rng.integers(3)] = 0.0                                        # a flat box
+        c = rng.normal(size=3) * 0.5
+        bmin, bmax = (c - half).astype(np.float32), (c + half).astype(np.float32)
+        tf = po.Transform(po.vec3(*(off + rng.normal(size=3))), po.vec3(*rng.uniform(-3.2, 3.2, size=3)))
+        centre = off + np.array([tf.position.x, tf.position.y, tf.position.z]) - off   # world position of the box, roughly
+        centre = np.array([tf.position.x, tf.position.y, tf.position.z])
+        dist = 10 ** rng.uniform(-0.5, 1.5) * (1.0 + float(half.max()))
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        eye = centre + d * dist
+        if trial % 7 == 3:
+            look = centre + rng.normal(size=3) * 3 * dist                       # looking past it (or away from it)
+        else:
+            look = centre + rng.normal(size=3) * float(half.max()) * rng.uniform(0, 3)
+        fov = float(rng.choice([1.0, 20.0, 60.0, 120.0]))
+        cam = po.Camera(po.vec3(*eye), po.vec3(*look), po.vec3(0, 1, 0), fov)
+        rect = emul.screen_rect(tf, bmin, bmax, cam, light, w, h)
+        assert 0 <= rect[0] <= rect[2] <= (w + 7) // 8 and 0 <= rect[1] <= rect[3] <= (h + 7) // 8
+        box = po.Aabb(po.vec3(*bmin), po.vec3(*bmax))
+        passes = np.zeros((h, w), bool)
+        for y in range(h):
+            for x in range(w):
+                ray = L.orc_camera_ray(C.byref(cam), np.float32((x + 0.5) / np.float32(w)), np.float32((y + 0.5) / np.float32(h)),
+                                       np.float32(w) / np.float32(h))
+                passes[y, x] = bool(L.orc_ray_aabb(L.orc_transform_ray(ray, tf), box))
+        inside = np.zeros((h, w), bool)
+        inside[rect[1] * 8:rect[3] * 8, rect[0] * 8:rect[2] * 8] = True
+        assert not (passes & ~inside).any(), f"trial {trial}: {int((passes & ~inside).sum())} rays pass the box outside {rect}"
+        if (rect[2] - rect[0]) * (rect[3] - rect[1]) < ((w + 7) // 8) * ((h + 7) // 8):
+            culled_somewhere += 1
+    assert culled_somewhere >= 15                                               # the rectangle is not trivially the whole frame
+
+
+def test_meshes_skipped_by_screen_rectangle_do_not_change_the_frame(po, em_default, golden_frames):
+    """The traversal as the kernels run it (no work counts: meshes outside their screen rectangle are skipped) on the
+    reference scene and on the scenes of tests/adversarial.py, against golden planes / the oracle."""
+    import adversarial
+    cam, light = po.default_camera(), po.default_light()
+    for f in (0, 45, 95):
+        got = em_default.render(cam, light, po.animation_transforms(f), 240, 135, screen_cull=True)
+        for k in ("rgb", "hit_id", "shadow"):
+            assert np.array_equal(got[k], golden_frames[f"f{f}_{k}"]), (f, k)
+        assert np.array_equal(bits(got["hit_t"]), bits(golden_frames[f"f{f}_hit_t"]))
+    tex = checker()
+    for name, soups, tfs, acam, w, h in adversarial.scenes(po, seed=9):
+        ms = adversarial.build(po, soups, tex)
+        s = emul.Scene(regroup=True)
+        for m in ms:
+            assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+        want = po.render_frame(ms, tfs, acam, light, w, h)
+        got = s.render(acam, light, tfs, w, h, screen_cull=True)
+        s.close()
+        assert np.array_equal(got["hit_id"], want.hit_id) and np.array_equal(got["rgb"], want.rgb), name
+        assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t)) and np.array_equal(got["shadow"], want.shadow), name
