@@ -61,8 +61,12 @@ RT_HD F3 sample_value(const FrameArgs& A, const SampleArgs& X, const Nodes& node
     float closest = 1e30f;
     int who = -1;
     Hit best = no_hit();
+    const int tile_x = px >> 3, tile_y = row >> 3;
     for (int m = 0; m < A.n_mesh; m++) {
         const MeshArgs& M = A.mesh[m];
+        // outside A.vis[m] (two pixels wider than the mesh's root box can reach: a sample stays inside its pixel) the root
+        // test fails for certain
+        if (!COUNT && (tile_x < A.vis[m][0] || tile_x >= A.vis[m][2] || tile_y < A.vis[m][1] || tile_y >= A.vis[m][3])) continue;
         const F3 ld = unit(xform_vector<4>(M.inv, wd));
         Hit h = no_hit();
         if (party.template closest<COUNT, false>(M, nodes, f3(M.cam_o), ld, recip(ld), closest, h, stack, work) && h.t < closest) {
