@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Where rt_render_frames spends its time, by leaving parts of the scene out: the whole scene, the ground replaced by two
+triangles (its walk costs nothing then), the ground alone, two triangles alone (the per-pixel fixed part).  ms per launch of
+8 frames at 1920x1080 over the bench's twelve launches.  Run on a GPU: python scripts/cost_split_frames.py"""
 import sys, os, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from raytracer_amd import capi, demo, host_api
 import bench

@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""The instanced stress frame (56 x 56 treasures + ground + drone) as it is and with every treasure replaced by an octahedron
+in its box: what is left then is the hierarchy over the instances and the per-pixel fixed part.  Prints kernel ms and box /
+triangle tests per ray.  Run on a GPU: python scripts/cost_split_instanced.py"""
 import sys, os, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from raytracer_amd import capi, demo, host_api
 scene = demo.DemoScene(0)

@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""24 instanced frames on one stream and alternating between two streams: if the frame were bound by its slowest tiles, two
+frames in flight would overlap.  Argument: option instanced_wave.  Run on a GPU: python scripts/instanced_overlap.py 0"""
 import sys, os, json, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from raytracer_amd import capi, demo
 scene = demo.DemoScene(0); ctx = scene.ctx

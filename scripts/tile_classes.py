@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Time of every 8x8 tile of a 1920x1080 frame (rt_set_trace_buffer), summed by what the tile's camera rays hit (sky, ground
+only, drone, treasure ...).  Tile times are residency, not instruction counts: a wave waiting for memory counts too.
+Run on a GPU: python scripts/tile_classes.py"""
 import sys, os, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from raytracer_amd import demo
 scene = demo.DemoScene(0); ctx = scene.ctx
