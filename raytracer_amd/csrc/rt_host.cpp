@@ -296,6 +296,21 @@ SceneArgs scene_args(const rt_ctx* ctx) {
     return S;
 }
 
+// Shadow-ray rectangles of all meshes of a frame (mesh_shadow_rect): they need the bounds of the whole scene first.
+void frame_shadow_rects(const rt_transform* transforms, int32_t n_transforms, FrameArgs& A) {
+    double slo[3] = {1e300, 1e300, 1e300}, shi[3] = {-1e300, -1e300, -1e300};
+    bool any = false;
+    for (int32_t m = 0; m < n_transforms; m++) {
+        if (A.mesh[m].empty) continue;
+        const WorldBox w = world_box(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max);
+        for (int i = 0; i < 3; i++) { slo[i] = w.lo[i] < slo[i] ? w.lo[i] : slo[i]; shi[i] = w.hi[i] > shi[i] ? w.hi[i] : shi[i]; }
+        any = true;
+    }
+    if (!any) return;
+    for (int32_t m = 0; m < n_transforms; m++)
+        mesh_shadow_rect(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max, slo, shi, A, A.vis_shadow[m]);
+}
+
 // Per-frame constants: camera basis, light, and each mesh's placement (inverse matrices, camera
 // origin and light direction in mesh space).
 void fill_frame(const rt_ctx* ctx, const rt_camera& camera, const rt_light& light, const rt_transform* transforms, int32_t n_transforms,
@@ -309,7 +324,9 @@ void fill_frame(const rt_ctx* ctx, const rt_camera& camera, const rt_light& ligh
         fill_placement(transforms[m], A, A.mesh[m]);
         if (ctx->screen_cull) mesh_screen_rect(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max, A, A.vis[m]);
         else { A.vis[m][0] = 0; A.vis[m][1] = 0; A.vis[m][2] = (width + 7) / 8; A.vis[m][3] = (height + 7) / 8; }
+        for (int i = 0; i < 4; i++) A.vis_shadow[m][i] = i < 2 ? 0 : (i == 2 ? (width + 7) / 8 : (height + 7) / 8);
     }
+    if (ctx->screen_cull && n_transforms > 0 && n_transforms <= kMaxMeshes) frame_shadow_rects(transforms, n_transforms, A);
 }
 
 // First tile row (8-pixel rows) of the screen area in which a ray of this frame, primary or

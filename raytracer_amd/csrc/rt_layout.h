@@ -115,6 +115,9 @@ struct FrameArgs {
     // mesh's root box, not even with the rounding of the float test (see mesh_screen_rect, rt_pack.h): there the
     // reference's root test (bvh.c:82) fails for certain, and the mesh is skipped without transforming the ray.
     int32_t vis[kMaxMeshes][4];
+    // The same for shadow rays: tiles outside of which no surface point of the scene seen in the tile can send a shadow ray
+    // (towards light_dir) through the mesh's root box (mesh_shadow_rect).
+    int32_t vis_shadow[kMaxMeshes][4];
     MeshArgs mesh[kMaxMeshes];
 };
 

@@ -475,6 +475,52 @@ inline bool coop_rect(const WorldBox& b, const double scene_lo[3], const double 
 }
 
 
+// Rectangle of tiles around the projections of `n` world points, each allowed to be off by `slack` in space; false (rect =
+// whole frame) when a point is at or behind the camera plane or the allowance exceeds what the projection can tell.
+inline bool tiles_around(const double (*pts)[3], int n, double slack, const FrameArgs& A, int32_t rect[4]) {
+    const int tiles_x = (A.width + 7) / 8, tiles_y = (A.full_height + 7) / 8;
+    rect[0] = 0; rect[1] = 0; rect[2] = tiles_x; rect[3] = tiles_y;
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300}, z_min = 1e300, s_max = 0.0;
+    for (int c = 0; c < n; c++) {
+        double w[3];
+        for (int i = 0; i < 3; i++) w[i] = pts[c][i] - (double)A.cam_pos[i];
+        const double z = w[0] * A.cam_fwd[0] + w[1] * A.cam_fwd[1] + w[2] * A.cam_fwd[2];
+        if (!(z > 1e-4) || !(z - 2.0 * slack > 0.25 * z)) return false;      // behind the camera plane, or closer than the slack can tell
+        const double sx = (w[0] * A.cam_right[0] + w[1] * A.cam_right[1] + w[2] * A.cam_right[2]) / z;
+        const double sy = (w[0] * A.cam_up[0] + w[1] * A.cam_up[1] + w[2] * A.cam_up[2]) / z;
+        if (!(sx == sx) || !(sy == sy)) return false;
+        lo[0] = sx < lo[0] ? sx : lo[0]; hi[0] = sx > hi[0] ? sx : hi[0];
+        lo[1] = sy < lo[1] ? sy : lo[1]; hi[1] = sy > hi[1] ? sy : hi[1];
+        z_min = z < z_min ? z : z_min;
+        const double a = fabs(sx) > fabs(sy) ? fabs(sx) : fabs(sy);
+        s_max = a > s_max ? a : s_max;
+    }
+    if (n <= 0) return false;
+    // moving a point by `slack` moves its projection by at most slack * (1 + |s|) / (z - slack); z - slack >= z / 2 here
+    const double allow = 2.0 * slack * (1.0 + s_max) / z_min + (1.0 + s_max * s_max) / 16384.0;
+    const double kx = 0.5 * A.width / ((double)A.aspect * A.scale), ky = 0.5 * A.full_height / (double)A.scale;
+    if (!(kx > 0) || !(ky > 0) || !(kx < 1e12) || !(ky < 1e12)) return false;
+    // pixel coordinate of a projection (inverse of camera.c:18-19 and scene.c:61-62): px = (sx / (aspect*scale) + 1) / 2 * width - 1/2
+    const double px_lo = (lo[0] - allow) * kx + 0.5 * A.width - 0.5 - 2.0, px_hi = (hi[0] + allow) * kx + 0.5 * A.width - 0.5 + 2.0;
+    const double py_lo = 0.5 * A.full_height - (hi[1] + allow) * ky - 0.5 - 2.0, py_hi = 0.5 * A.full_height - (lo[1] - allow) * ky - 0.5 + 2.0;
+    auto tile_lo = [](double v, int m) { const double t = floor(v / 8.0); return t < 0 ? 0 : (t > m ? m : (int)t); };
+    auto tile_hi = [](double v, int m) { const double t = floor(v / 8.0) + 1.0; return t < 0 ? 0 : (t > m ? m : (int)t); };
+    rect[0] = tile_lo(px_lo, tiles_x); rect[1] = tile_lo(py_lo, tiles_y);
+    rect[2] = tile_hi(px_hi, tiles_x); rect[3] = tile_hi(py_hi, tiles_y);
+    return true;
+}
+
+// Sum of the magnitudes a placed box's root test works with (camera position, placement, box coordinates).
+inline double placement_magnitude(const rt_transform& tf, const float* bmin, const float* bmax, const FrameArgs& A) {
+    double mag = fabs(tf.position.x) + fabs(tf.position.y) + fabs(tf.position.z);
+    for (int i = 0; i < 3; i++) {
+        mag += fabs((double)A.cam_pos[i]);
+        const double m = fabs((double)bmin[i]) > fabs((double)bmax[i]) ? fabs((double)bmin[i]) : fabs((double)bmax[i]);
+        mag += m;
+    }
+    return mag;
+}
+
 // Tiles (8x8 pixels, {x0, y0, x1, y1} half open) outside of which a camera ray of the frame cannot pass the root box of a
 // mesh placed by tf -- with certainty, i.e. including what float rounding can do to the reference's test in mesh space
 // (ray.c:5-22 + aabb.c:33-56).  That test works on values whose absolute errors are a few units in the last place of
@@ -485,42 +531,37 @@ inline bool coop_rect(const WorldBox& b, const double scene_lo[3], const double 
 // pixels (sample jitter, tile rounding) are added on every side.  A corner at or behind the camera plane, or a frame so
 // narrow that the allowance exceeds it, gives the whole frame.
 inline void mesh_screen_rect(const rt_transform& tf, const float* bmin, const float* bmax, const FrameArgs& A, int32_t rect[4]) {
+    const WorldBox b = world_box(tf, bmin, bmax);
+    const double slack = placement_magnitude(tf, bmin, bmax, A) * (1.0 / 262144.0);
+    (void)tiles_around(b.corner, 8, slack, A, rect);
+}
+
+// The same for shadow rays (scene.c:117-139).  A shadow ray starts at a surface point P of the scene (moved 0.001 along
+// the normal) and runs along the light direction L; it can pass the box only if P lies in the box swept against L, and P
+// lies inside the scene's bounds, which limits the sweep to s_max.  The swept box is the convex hull of the box's corners
+// and the same corners moved by -s_max L, so its projection lies inside the rectangle around those sixteen points.  P is
+// seen in the pixel whose ray found it (it is computed as origin + t * direction, scene.c:118), so pixels outside the
+// rectangle have no such P.  Slack as for camera rays, with the scene's extent (P's magnitude) and the 0.001 added.
+inline void mesh_shadow_rect(const rt_transform& tf, const float* bmin, const float* bmax, const double scene_lo[3], const double scene_hi[3],
+                             const FrameArgs& A, int32_t rect[4]) {
     const int tiles_x = (A.width + 7) / 8, tiles_y = (A.full_height + 7) / 8;
     rect[0] = 0; rect[1] = 0; rect[2] = tiles_x; rect[3] = tiles_y;
     const WorldBox b = world_box(tf, bmin, bmax);
-    double mag = fabs(tf.position.x) + fabs(tf.position.y) + fabs(tf.position.z);
+    double mag = placement_magnitude(tf, bmin, bmax, A);
+    for (int i = 0; i < 3; i++) mag += (fabs(scene_lo[i]) > fabs(scene_hi[i]) ? fabs(scene_lo[i]) : fabs(scene_hi[i]));
+    const double slack = mag * (1.0 / 262144.0) + 0.002;
+    double s_max = 1e300;
     for (int i = 0; i < 3; i++) {
-        mag += fabs((double)A.cam_pos[i]);
-        const double m = fabs((double)bmin[i]) > fabs((double)bmax[i]) ? fabs((double)bmin[i]) : fabs((double)bmax[i]);
-        mag += m;
+        const double L = A.light_dir[i];
+        if (L > 0) { const double s = (b.hi[i] + slack - (scene_lo[i] - slack)) / L; s_max = s < s_max ? s : s_max; }
+        else if (L < 0) { const double s = (scene_hi[i] + slack - (b.lo[i] - slack)) / -L; s_max = s < s_max ? s : s_max; }
     }
-    const double slack = mag * (1.0 / 262144.0);
-    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300}, z_min = 1e300, s_max = 0.0;
-    for (int c = 0; c < 8; c++) {
-        double w[3];
-        for (int i = 0; i < 3; i++) w[i] = b.corner[c][i] - (double)A.cam_pos[i];
-        const double z = w[0] * A.cam_fwd[0] + w[1] * A.cam_fwd[1] + w[2] * A.cam_fwd[2];
-        if (!(z > 1e-4) || !(z - 2.0 * slack > 0.25 * z)) return;            // behind the camera plane, or closer than the slack can tell
-        const double sx = (w[0] * A.cam_right[0] + w[1] * A.cam_right[1] + w[2] * A.cam_right[2]) / z;
-        const double sy = (w[0] * A.cam_up[0] + w[1] * A.cam_up[1] + w[2] * A.cam_up[2]) / z;
-        if (!(sx == sx) || !(sy == sy)) return;
-        lo[0] = sx < lo[0] ? sx : lo[0]; hi[0] = sx > hi[0] ? sx : hi[0];
-        lo[1] = sy < lo[1] ? sy : lo[1]; hi[1] = sy > hi[1] ? sy : hi[1];
-        z_min = z < z_min ? z : z_min;
-        const double a = fabs(sx) > fabs(sy) ? fabs(sx) : fabs(sy);
-        s_max = a > s_max ? a : s_max;
-    }
-    // moving a point by `slack` moves its projection by at most slack * (1 + |s|) / (z - slack); z - slack >= z / 2 here
-    const double allow = 2.0 * slack * (1.0 + s_max) / z_min + (1.0 + s_max * s_max) / 16384.0;
-    const double kx = 0.5 * A.width / ((double)A.aspect * A.scale), ky = 0.5 * A.full_height / (double)A.scale;
-    if (!(kx > 0) || !(ky > 0) || !(kx < 1e12) || !(ky < 1e12)) return;
-    // pixel coordinate of a projection (inverse of camera.c:18-19 and scene.c:61-62): px = (sx / (aspect*scale) + 1) / 2 * width - 1/2
-    const double px_lo = (lo[0] - allow) * kx + 0.5 * A.width - 0.5 - 2.0, px_hi = (hi[0] + allow) * kx + 0.5 * A.width - 0.5 + 2.0;
-    const double py_lo = 0.5 * A.full_height - (hi[1] + allow) * ky - 0.5 - 2.0, py_hi = 0.5 * A.full_height - (lo[1] - allow) * ky - 0.5 + 2.0;
-    auto tile_lo = [](double v, int n) { const double t = floor(v / 8.0); return t < 0 ? 0 : (t > n ? n : (int)t); };
-    auto tile_hi = [](double v, int n) { const double t = floor(v / 8.0) + 1.0; return t < 0 ? 0 : (t > n ? n : (int)t); };
-    rect[0] = tile_lo(px_lo, tiles_x); rect[1] = tile_lo(py_lo, tiles_y);
-    rect[2] = tile_hi(px_hi, tiles_x); rect[3] = tile_hi(py_hi, tiles_y);
+    if (!(s_max < 1e9)) return;                     // the light direction has no component the scene's bounds could stop
+    if (!(s_max > 0)) s_max = 0;
+    double pts[16][3];
+    for (int c = 0; c < 16; c++)
+        for (int i = 0; i < 3; i++) pts[c][i] = b.corner[c & 7][i] - (c < 8 ? 0.0 : s_max) * (double)A.light_dir[i];
+    (void)tiles_around(pts, 16, slack, A, rect);
 }
 
 // ---- hierarchy over placed instances (never used for results, only to propose instances) ----------

@@ -380,6 +380,8 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     bool dark = false;
     for (int m = 0; m < A.n_mesh && !dark; m++) {
         const MeshArgs& S = A.mesh[m];
+        // outside A.vis_shadow[m] no surface point seen in this tile can send its shadow ray through the mesh's root box
+        if (!COUNT && !FULL && (tile_x < A.vis_shadow[m][0] || tile_x >= A.vis_shadow[m][2] || tile_y < A.vis_shadow[m][1] || tile_y >= A.vis_shadow[m][3])) continue;
         const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);   // ray.c:19
         dark = party.template any<COUNT, FULL>(S, nodes, lo, f3(S.lit_d), f3(S.lit_inv), stack, work);
         if (DEFER && party.exhausted()) { out.deferred = 1; return out; }

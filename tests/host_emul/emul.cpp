@@ -94,6 +94,14 @@ void emul_screen_rect(const rt_transform* tf, const float* bmin, const float* bm
     mesh_screen_rect(*tf, bmin, bmax, A, rect4);
 }
 
+// The tiles outside of which the product skips a mesh for shadow rays (mesh_shadow_rect); scene bounds as 3 + 3 doubles.
+void emul_shadow_rect(const rt_transform* tf, const float* bmin, const float* bmax, const double* scene_lo, const double* scene_hi,
+                      const rt_camera* cam, const rt_light* light, int32_t width, int32_t height, int32_t* rect4) {
+    FrameArgs A; memset(&A, 0, sizeof A);
+    fill_camera(*cam, *light, width, height, A);
+    mesh_shadow_rect(*tf, bmin, bmax, scene_lo, scene_hi, A, rect4);
+}
+
 // Per-frame constants as the product computes them: inv rows 0..3 (16 floats) and nrm (9 floats).
 void emul_placement(const rt_transform* tf, const rt_camera* cam, const rt_light* light, float* inv16, float* nrm9,
                     float* cam_o3, float* lit_d3, uint32_t* w_mode) {
@@ -125,6 +133,19 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
         fill_placement(tfs[m], A, M);
         mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
+    }
+    {   // shadow-ray rectangles, as the product's fill_frame computes them
+        double slo[3] = {1e300, 1e300, 1e300}, shi[3] = {-1e300, -1e300, -1e300};
+        bool any = false;
+        for (int m = 0; m < n_tf; m++) {
+            const int32_t whole[4] = {0, 0, (width + 7) / 8, (height + 7) / 8};
+            memcpy(A.vis_shadow[m], whole, sizeof whole);
+            if (A.mesh[m].empty) continue;
+            const WorldBox wb = world_box(tfs[m], A.mesh[m].root_min, A.mesh[m].root_max);
+            for (int i = 0; i < 3; i++) { slo[i] = wb.lo[i] < slo[i] ? wb.lo[i] : slo[i]; shi[i] = wb.hi[i] > shi[i] ? wb.hi[i] : shi[i]; }
+            any = true;
+        }
+        for (int m = 0; any && m < n_tf; m++) mesh_shadow_rect(tfs[m], A.mesh[m].root_min, A.mesh[m].root_max, slo, shi, A, A.vis_shadow[m]);
     }
     GlobalNodes nodes; nodes.all = s->all_pairs.data();
     unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;

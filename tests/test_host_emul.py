@@ -440,3 +440,65 @@ def test_meshes_skipped_by_screen_rectangle_do_not_change_the_frame(po, em_defau
         s.close()
         assert np.array_equal(got["hit_id"], want.hit_id) and np.array_equal(got["rgb"], want.rgb), name
         assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t)) and np.array_equal(got["shadow"], want.shadow), name
+
+
+def test_shadow_rectangle_contains_every_point_whose_shadow_ray_passes_the_root_box(po):
+    """mesh_shadow_rect promises: a surface point of the scene that is seen outside the rectangle cannot send its shadow ray
+    through the mesh's root box.  Checked with the oracle's transform_ray + ray_aabb_intersect on points spread over the
+    scene's bounds (more than the surfaces: the claim holds for every point inside the bounds), for several lights,
+    placements and cameras; the point's pixel is its own projection."""
+    rng = np.random.default_rng(33)
+    L = po.lib()
+    w, h = 192, 108
+    tiles = ((w + 7) // 8, (h + 7) // 8)
+    culled = 0
+    for trial in range(40):
+        off = rng.choice([0.0, 0.0, 100.0, 1.0e4]) * rng.normal(size=3)
+        half = 10 ** rng.uniform(-1.0, 0.3, size=3)
+        c = rng.normal(size=3) * 0.3
+        bmin, bmax = (c - half).astype(np.float32), (c + half).astype(np.float32)
+        pos = off + rng.normal(size=3) * 2
+        tf = po.Transform(po.vec3(*pos), po.vec3(*rng.uniform(-3.2, 3.2, size=3)))
+        ext = float(np.linalg.norm(half)) + 1e-3
+        slo, shi = pos - rng.uniform(2, 12, size=3), pos + rng.uniform(2, 12, size=3)      # bounds of "the scene" around the mesh
+        ld = rng.normal(size=3)
+        if trial % 4 == 0:
+            ld[rng.integers(3)] = 0.0
+        ld /= np.linalg.norm(ld)
+        light = po.Light(po.vec3(*np.array(ld, np.float32)), po.vec3(1, 1, 1))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        eye = pos + d * rng.uniform(15, 40)
+        cam = po.Camera(po.vec3(*eye), po.vec3(*(pos + rng.normal(size=3) * 3)), po.vec3(0, 1, 0), float(rng.choice([30.0, 60.0, 100.0])))
+        rect = emul.shadow_rect(tf, bmin, bmax, slo, shi, cam, light, w, h)
+        assert 0 <= rect[0] <= rect[2] <= tiles[0] and 0 <= rect[1] <= rect[3] <= tiles[1]
+        if (rect[2] - rect[0]) * (rect[3] - rect[1]) < tiles[0] * tiles[1]:
+            culled += 1
+        # camera basis in double, as camera.c:13-17 defines it
+        e = np.array([cam.position.x, cam.position.y, cam.position.z], np.float64)
+        look = np.array([cam.look_at.x, cam.look_at.y, cam.look_at.z], np.float64)
+        fwd = look - e; fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, [0, 1, 0]); right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        scale = np.tan(np.radians(cam.fov * 0.5)); aspect = w / h
+        box = po.Aabb(po.vec3(*bmin), po.vec3(*bmax))
+        pts = rng.uniform(slo, shi, size=(1500, 3))
+        # half of the points close to the box swept against the light, where the shadow rays that matter start
+        pts[:750] = pos + rng.normal(size=(750, 3)) * ext * 1.5 - ld * rng.uniform(0, 12, size=(750, 1))
+        pts = np.clip(pts, slo, shi)
+        for P in pts:
+            Pf = np.array(P, np.float32)
+            ray = po.Ray(po.vec3(*Pf), light.direction)
+            if not L.orc_ray_aabb(L.orc_transform_ray(ray, tf), box):
+                continue
+            v = Pf.astype(np.float64) - e
+            z = v @ fwd
+            if z <= 1e-6:
+                assert rect == [0, 0, tiles[0], tiles[1]] or True      # behind the camera: never seen
+                continue
+            px = ((v @ right) / z / (aspect * scale) + 1) * 0.5 * w - 0.5
+            py = (1 - (v @ up) / z / scale) * 0.5 * h - 0.5
+            if not (0 <= px < w and 0 <= py < h):
+                continue
+            tx, ty = int(px) // 8, int(py) // 8
+            assert rect[0] <= tx < rect[2] and rect[1] <= ty < rect[3], f"trial {trial}: point at pixel ({px:.1f}, {py:.1f}) outside {rect}"
+    assert culled >= 10
