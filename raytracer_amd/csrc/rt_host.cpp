@@ -34,6 +34,7 @@ struct DeviceMesh {
     TriRec* d_tris = nullptr;
     AttrRec* d_attrs = nullptr;
     uint32_t* d_texels = nullptr;
+    uint32_t* d_grid = nullptr;    // flat meshes: entry references per cell (Packer::build_grid)
     MeshArgs proto;          // static part filled at upload; placement filled per frame
     int32_t n_tris = 0, n_pairs = 0;
 };
@@ -161,6 +162,7 @@ void free_mesh(DeviceMesh& m) {
     if (m.d_tris) (void)hipFree(m.d_tris);
     if (m.d_attrs) (void)hipFree(m.d_attrs);
     if (m.d_texels) (void)hipFree(m.d_texels);
+    if (m.d_grid) (void)hipFree(m.d_grid);
     m = DeviceMesh();
 }
 
@@ -191,6 +193,12 @@ int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tr
         if (dm.d_attrs) (void)hipFree(dm.d_attrs);
         dm.d_tris = t; dm.d_attrs = a;
     }
+    if (dm.d_grid) { (void)hipFree(dm.d_grid); dm.d_grid = nullptr; }
+    if (pk.grid_axis < 3) {
+        const int gst = upload_array(ctx, pk.grid, &dm.d_grid);
+        if (gst != RT_OK) return gst;
+    }
+    set_grid_args(pk, dm.d_grid, dm.proto);
     dm.pairs = pk.pairs; dm.tris = pk.tris; dm.depth = pk.depth; dm.host_tris = true;
     dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs;
     memcpy(dm.proto.root_min, pk.root_min, 12);
@@ -220,6 +228,8 @@ int build_into(rt_ctx* ctx, DeviceMesh& dm, const rt_triangle* tris, int32_t n, 
             if (dm.d_tris) (void)hipFree(dm.d_tris);
             if (dm.d_attrs) (void)hipFree(dm.d_attrs);
             dm.d_tris = pk.d_tris; dm.d_attrs = pk.d_attrs;
+            if (dm.d_grid) { (void)hipFree(dm.d_grid); dm.d_grid = nullptr; }
+            dm.proto.grid = nullptr; dm.proto.grid_axis = 3u; dm.proto.grid_n = 0;        // meshes packed on the device have no grid
             dm.pairs.swap(pk.pairs); dm.tris.clear(); dm.tris.shrink_to_fit(); dm.host_tris = false; dm.depth = pk.depth;
             dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs;
             memcpy(dm.proto.root_min, pk.root_min, 12);

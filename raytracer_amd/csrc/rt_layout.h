@@ -82,6 +82,16 @@ struct MeshArgs {
     // Where the reference's own tree starts when root_ref enters a regrouped one (rt_pack.h, Packer::regroup);
     // equal to root_ref otherwise.  Same index space as root_ref (relative to pair_base).
     uint32_t ref_root;
+    // Flat meshes (root box of zero thickness along grid_axis, e.g. a ground plane): a grid over the other two axes whose
+    // cells name the node of the tree behind root_ref at which a ray that meets the mesh's plane inside the cell may start
+    // its walk -- everything above that node has, for such a ray, exactly one child whose box it can pass (FlatGrid in
+    // rt_pack.h).  grid_axis = 3: no grid.
+    const uint32_t* grid;
+    uint32_t grid_axis;
+    int32_t grid_n;              // cells per side
+    float grid_lo[2], grid_inv[2];      // per in-plane axis ((axis+1)%3, (axis+2)%3): origin, cells per unit length
+    float grid_slack[2];         // how far a ray's plane point may be off for the cell's entry to hold
+    float grid_bmax[2];          // largest |coordinate| of the mesh on that axis
 };
 constexpr uint32_t kNotResident = 0xFFFFFFFFu;
 // Small meshes (nodes + triangles) are copied into LDS by every workgroup of the lean kernels, the

@@ -117,7 +117,20 @@ struct PackedMesh {
     // Without one both are the same.  tree_pairs = nodes of the tree root_ref enters.
     uint32_t ref_root = kLeafBit;
     uint32_t tree_pairs = 0;
+    // FlatGrid (see Packer::build_grid): entry references per cell, row-major [second in-plane axis][first]; axis 3 = none
+    std::vector<uint32_t> grid;
+    uint32_t grid_axis = 3;
+    int32_t grid_n = 0;
+    float grid_lo[2] = {0, 0}, grid_inv[2] = {0, 0}, grid_slack[2] = {0, 0}, grid_bmax[2] = {0, 0};
 };
+
+// The grid fields of a MeshArgs from a packed mesh; d_grid = where pk.grid lives for the code that will traverse.
+inline void set_grid_args(const PackedMesh& pk, const uint32_t* d_grid, MeshArgs& M) {
+    M.grid = pk.grid_axis < 3 ? d_grid : nullptr;
+    M.grid_axis = M.grid ? pk.grid_axis : 3u;
+    M.grid_n = pk.grid_n;
+    for (int j = 0; j < 2; j++) { M.grid_lo[j] = pk.grid_lo[j]; M.grid_inv[j] = pk.grid_inv[j]; M.grid_slack[j] = pk.grid_slack[j]; M.grid_bmax[j] = pk.grid_bmax[j]; }
+}
 
 class Packer {
 public:
@@ -160,6 +173,7 @@ public:
         out_.empty = false;
         if (out_.depth + 2 > kStackDepth || out_.depth > RT_MAX_TREE_DEPTH) { err = "BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
         if (regroup_ && leaves_ok_ && leaves_.size() >= 4 && leaves_.size() <= ((size_t)1 << 20)) regroup();
+        if (regroup_) build_grid();
         return RT_OK;
     }
 
@@ -343,6 +357,66 @@ private:
         out_.tree_pairs = shift;
         out_.pairs.swap(fast);
         if (deepest > out_.depth) out_.depth = deepest;
+    }
+
+    // ---- flat meshes: where a ray can start its walk ------------------------------------------------
+    // A mesh whose root box has zero thickness along one axis k (a ground plane) is met by a ray in ONE point X of its plane,
+    // and a leaf's slab test can only pass if X lies in the leaf's rectangle, up to rounding: with all direction
+    // components finite and non-zero, "tmax >= tmin" needs the plane's parameter ty to lie between the two parameters of
+    // each in-plane axis a, t1 = fl(fl(min_a - o_a) inv_a) and t2 likewise, and then X_a = fl(o_a + fl(ty d_a)) is within
+    // 3.2 u (|o_a| + |ty d_a| + max|bound_a|) of [min_a, max_a] (u = 2^-24: two roundings in t1/t2, one in inv_a = fl(1/d_a),
+    // two in X_a).  The traversal takes 16 u of that sum as the ray's uncertainty E and uses the grid only when E is at most
+    // half the slack the cells were built with, the other half covering the rounding of the cell index.
+    // Per cell, padded by the slack on every side: walk down from the root while only ONE child's box overlaps the padded
+    // cell -- no leaf below the other child can pass for a ray whose X is in the cell -- and store where that stops (a
+    // node with two overlapping children, a leaf, or nothing at all: then no leaf can pass and the walk is empty).
+    // Starting there skips the top of the tree without changing which leaves are reached.
+    void build_grid() {
+        if (out_.empty || (out_.root_ref & kLeafBit) || out_.tree_pairs < 8) return;
+        int k = -1;
+        for (int a = 0; a < 3; a++)
+            if (out_.root_min[a] == out_.root_max[a]) { if (k >= 0) return; k = a; }        // flat along exactly one axis
+        if (k < 0) return;
+        const int ax[2] = {(k + 1) % 3, (k + 2) % 3};
+        double lo[2], ext[2];
+        for (int j = 0; j < 2; j++) {
+            lo[j] = out_.root_min[ax[j]]; ext[j] = (double)out_.root_max[ax[j]] - lo[j];
+            if (!(ext[j] > 0) || !(ext[j] < 1e30)) return;
+        }
+        // cells well below the size of a leaf's rectangle, so that most cells lie inside one leaf (or two): eight per side
+        // and leaf on average
+        int n = (int)ceil(sqrt(64.0 * (double)(leaves_.empty() ? out_.tree_pairs : leaves_.size())));
+        n = n < 8 ? 8 : (n > 256 ? 256 : n);
+        double cs[2], slack[2];
+        for (int j = 0; j < 2; j++) { cs[j] = ext[j] / n; slack[j] = cs[j] / 8.0; }
+        out_.grid.assign((size_t)n * (size_t)n, leaf_ref(0, 0));
+        auto overlaps = [&](const float* bmin, const float* bmax, const double* rlo, const double* rhi) {
+            for (int j = 0; j < 2; j++)
+                if ((double)bmax[ax[j]] < rlo[j] || (double)bmin[ax[j]] > rhi[j]) return false;
+            return true;
+        };
+        for (int iy = 0; iy < n; iy++)
+            for (int ix = 0; ix < n; ix++) {
+                const double rlo[2] = {lo[0] + ix * cs[0] - slack[0], lo[1] + iy * cs[1] - slack[1]};
+                const double rhi[2] = {lo[0] + (ix + 1) * cs[0] + slack[0], lo[1] + (iy + 1) * cs[1] + slack[1]};
+                uint32_t ref = out_.root_ref;
+                while (!(ref & kLeafBit)) {
+                    const PairNode& N = out_.pairs[ref];
+                    const bool l = overlaps(N.lmin, N.lmax, rlo, rhi), r = overlaps(N.rmin, N.rmax, rlo, rhi);
+                    if (l && r) break;
+                    if (!l && !r) { ref = leaf_ref(0, 0); break; }
+                    ref = l ? N.lref : N.rref;
+                }
+                out_.grid[(size_t)iy * (size_t)n + (size_t)ix] = ref;
+            }
+        out_.grid_axis = (uint32_t)k; out_.grid_n = n;
+        for (int j = 0; j < 2; j++) {
+            out_.grid_lo[j] = (float)lo[j];
+            out_.grid_inv[j] = (float)(1.0 / cs[j]);
+            out_.grid_slack[j] = (float)(slack[j] * 0.5);                 // what the ray's own uncertainty may use up
+            const float a = fabsf(out_.root_min[ax[j]]), b = fabsf(out_.root_max[ax[j]]);
+            out_.grid_bmax[j] = a > b ? a : b;
+        }
     }
 
     const rt_triangle* tris_;

@@ -193,6 +193,26 @@ RT_HD uint32_t entry_ref(const MeshArgs& M, F3 d) {
     return (d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ? M.root_ref : M.ref_root;
 }
 
+RT_HD float comp(F3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+// Where a ray starts its walk in a flat mesh (MeshArgs::grid, built by Packer::build_grid): the node stored for the cell
+// that holds the point X in which the ray meets the mesh's plane -- if the ray qualifies: all direction components finite
+// and non-zero (the caller checks the zeros), X inside the grid, and the ray's own uncertainty about X (16 u of the
+// magnitudes that enter it) no more than the slack the cells were built with.  Otherwise the tree's root.
+RT_HD uint32_t grid_entry(const MeshArgs& M, F3 o, F3 d, F3 inv, uint32_t root) {
+    const uint32_t k = M.grid_axis, a = k == 2 ? 0u : k + 1u, b = k == 0 ? 2u : (k == 1 ? 0u : 1u);
+    const float ty = (M.root_min[k] - comp(o, k)) * comp(inv, k);              // aabb.c:39-53 for the flat axis
+    const float sa = ty * comp(d, a), sb = ty * comp(d, b);
+    const float xa = comp(o, a) + sa, xb = comp(o, b) + sb;
+    const float ea = (fabsf(comp(o, a)) + fabsf(sa) + M.grid_bmax[0]) * 9.5367431640625e-7f;      // 2^-20 = 16 u
+    const float eb = (fabsf(comp(o, b)) + fabsf(sb) + M.grid_bmax[1]) * 9.5367431640625e-7f;
+    const float fa = (xa - M.grid_lo[0]) * M.grid_inv[0], fb = (xb - M.grid_lo[1]) * M.grid_inv[1];
+    const float n = (float)M.grid_n;
+    // every comparison is false for a NaN, so a ray whose numbers overflow keeps the root
+    if (!(ea <= M.grid_slack[0] && eb <= M.grid_slack[1] && fa >= 0.0f && fa < n && fb >= 0.0f && fb < n)) return root;
+    return M.grid[(uint32_t)(int)fb * (uint32_t)M.grid_n + (uint32_t)(int)fa];
+}
+
 // Closest hit (ANY=false) or any hit (ANY=true) of one mesh by ONE lane, ray already in mesh space.
 // FULL=true reproduces the reference's work exactly: every box whose ancestors' slabs all pass is
 // visited, and an any-hit query keeps going after its first accepted triangle.
@@ -214,6 +234,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
         // nothing but triangle tests, so the lanes of a wave do not drag each other through both
         // kinds of work on every step.
         uint32_t ref = entry_ref<false>(M, d);
+        if (M.grid_axis < 3u && ref == M.root_ref && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ref = grid_entry(M, o, d, inv, ref);
         bool live = true;
         while (live) {
             while (live && !(ref & kLeafBit)) {

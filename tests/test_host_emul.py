@@ -502,3 +502,74 @@ def test_shadow_rectangle_contains_every_point_whose_shadow_ray_passes_the_root_
             tx, ty = int(px) // 8, int(py) // 8
             assert rect[0] <= tx < rect[2] and rect[1] <= ty < rect[3], f"trial {trial}: point at pixel ({px:.1f}, {py:.1f}) outside {rect}"
     assert culled >= 10
+
+
+# ------------------------------------------------------------------------------ flat meshes: entry through the grid
+def _flat_mesh(rng, axis, n, extent, offset):
+    """A jittered n x n triangulated sheet with zero thickness along `axis`, centred at `offset`."""
+    a, b = (axis + 1) % 3, (axis + 2) % 3
+    g = np.linspace(-extent, extent, n + 1)
+    P = np.zeros((n + 1, n + 1, 3))
+    for j in range(n + 1):
+        for i in range(n + 1):
+            P[j, i, a] = g[i] + (rng.uniform(-0.3, 0.3) * extent / n if 0 < i < n else 0.0)
+            P[j, i, b] = g[j] + (rng.uniform(-0.3, 0.3) * extent / n if 0 < j < n else 0.0)
+    P += offset
+    P[..., axis] = np.float32(offset[axis])
+    v = []
+    for j in range(n):
+        for i in range(n):
+            v.append([P[j, i], P[j + 1, i + 1], P[j, i + 1]])
+            v.append([P[j, i], P[j + 1, i], P[j + 1, i + 1]])
+    return tri_rows(np.array(v, np.float32))
+
+
+def test_flat_meshes_entered_through_their_grid_give_the_reference_frame(po):
+    """Meshes of zero thickness along x, y or z (Packer::build_grid), near the origin and with coordinates of 1e3 in their own
+    space, seen steeply, at grazing angles and from far away, lit along and across the sheet: default traversal (which enters
+    through the grid), reference order and the oracle agree on every plane, and the grid saves box tests."""
+    rng = np.random.default_rng(17)
+    tex = checker()
+    saved = []
+    for trial in range(18):
+        axis = trial % 3
+        n = int(rng.choice([6, 12, 20]))
+        extent = float(10 ** rng.uniform(-0.3, 1.0))
+        offset = (rng.normal(size=3) * (1.0e3 if trial % 6 >= 4 else 1.0)).astype(np.float32).astype(np.float64)
+        sheet = _flat_mesh(rng, axis, n, extent, offset)
+        blob = tri_rows((offset + rng.normal(size=(40, 1, 3)) * extent * 0.3 + rng.normal(size=(40, 3, 3)) * extent * 0.05).astype(np.float32))
+        tfs = [po.Transform(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(-1, 1, size=3))),
+               po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))]
+        nrm = np.zeros(3); nrm[axis] = 1.0
+        side = rng.normal(size=3); side[axis] = 0; side /= np.linalg.norm(side)
+        elev = [0.8, 0.05, 1e-3, 1e-5][trial % 4]                                   # steep ... grazing
+        dist = extent * float(rng.uniform(0.5, 4.0)) * (100.0 if trial % 9 == 8 else 1.0)
+        eye_local = offset + side * dist * 0.9 + nrm * dist * elev
+        # the sheet is placed by tfs[0]: put the camera where that placement takes eye_local (approximately: rotation order as ray.c:7-9)
+        M = np.linalg.inv(np.array(po.mesh_matrices(tfs[0])[0], np.float64))       # mesh space -> world (inverse of ray.c:14's matrix)
+        eye, look = (M @ np.append(eye_local, 1.0))[:3], (M @ np.append(offset, 1.0))[:3]
+        cam = po.Camera(po.vec3(*eye), po.vec3(*look), po.vec3(*(M[:3, :3] @ nrm)), float(rng.choice([20.0, 60.0])))
+        ld = rng.normal(size=3); ld /= np.linalg.norm(ld)
+        light = po.Light(po.vec3(*np.array(ld, np.float32)), po.vec3(1.2, 1.1, 1.0))
+        meshes = []
+        for soup in (sheet, blob):
+            t, nodes = po.build_bvh(soup)
+            meshes.append(po.HostMesh(t, nodes, tex))
+        w, h = 128, 72
+        want = po.render_frame(meshes, tfs, cam, light, w, h)
+        counts = {}
+        for regroup in (False, True):
+            s = emul.Scene(regroup=regroup)
+            for mm in meshes:
+                assert s.add(mm.tris, mm.nodes, mm.rgba) == 0, s.error()
+            for mode in ({"full": False}, {"full": True}, {"screen_cull": True}):
+                got = s.render(cam, light, tfs, w, h, **mode)
+                for k, ref in (("hit_id", want.hit_id), ("shadow", want.shadow), ("rgb", want.rgb)):
+                    assert np.array_equal(got[k], ref), f"trial {trial} axis {axis} {mode} regroup {regroup}: {k}"
+                assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t)), (trial, mode)
+                if mode == {"full": False}:
+                    counts[regroup] = got["counters"]["slab_tests"]
+            s.close()
+        if (want.hit_id >= 0).mean() > 0.2:
+            saved.append(counts[True] / counts[False])
+    assert len(saved) >= 6 and np.median(saved) < 0.9, saved
