@@ -80,10 +80,10 @@ def frame_sequence(share, n):
     return [share[(k * FRAME_STRIDE) % len(share)] for k in range(n)]
 
 
-def spawn_ranks(a, argv):
-    """Starts N ranks of this program under torch.distributed.run as a child process and relays rank 0's
-    JSON line.  Nothing in this process has initialised a GPU (torch is not even imported here), and the
-    children are fresh interpreters."""
+def spawn_ranks(a, argv, script=None, marker='"metric"'):
+    """Starts N ranks of this program (or of `script`) under torch.distributed.run as a child process and relays
+    rank 0's JSON line (the stdout line that holds `marker`).  Nothing in this process has initialised a GPU
+    (torch is not even imported here), and the children are fresh interpreters."""
     port = a.master_port
     if not port:
         s = socket.socket()
@@ -91,21 +91,21 @@ def spawn_ranks(a, argv):
         port = s.getsockname()[1]
         s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(script or __file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
     for ln in proc.stdout.splitlines():
-        if ln.startswith("{") and '"metric"' in ln:
+        if ln.startswith("{") and marker in ln:
             line = ln
         else:
             print(ln, file=sys.stderr)
     if proc.returncode != 0:
-        sys.exit(f"bench.py: the {a.gpus}-rank run failed (torch.distributed.run exit code {proc.returncode})")
+        sys.exit(f"{os.path.basename(script or __file__)}: the {a.gpus}-rank run failed (torch.distributed.run exit code {proc.returncode})")
     if line is None:
-        sys.exit("bench.py: the ranks finished without a result line")
+        sys.exit(f"{os.path.basename(script or __file__)}: the ranks finished without a result line")
     print(line, flush=True)
 
 

@@ -91,3 +91,32 @@ def test_host_api_deals_frames_over_a_gpu_list():
     finally:
         L.rt_host_set_frames_in_flight(1)
         L.rt_host_set_gpus(None, 0)
+
+
+def _animation_job(*args):
+    import subprocess
+    import sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "animation_job.py"), *args], capture_output=True, text=True,
+                          timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"job"' in ln]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_the_whole_animation_as_one_job_equals_the_compiled_reference(tmp_path):
+    """The reference driver's 96 frames at its own size, rendered in batches and handed to the animation writer: the hash
+    over all frames is the compiled reference's, and the file holds 96 frames."""
+    out = str(tmp_path / "job.webp")
+    got = _animation_job("--out", out)
+    assert got["frames"] == 96 and got["equals_compiled_reference"] is True
+    assert os.path.getsize(out) > 100_000
+
+
+@pytest.mark.gpu
+def test_the_animation_job_over_two_ranks_gathers_the_same_frames():
+    """Two ranks on the one GPU, frames gathered through gloo: rank 0 ends up with the same 96 frames in order."""
+    got = _animation_job("--gpus", "2", "--backend", "gloo", "--one-device")
+    assert got["n_gpus"] == 2 and got["frames"] == 96 and got["equals_compiled_reference"] is True
