@@ -72,6 +72,8 @@ def lib():
         L.emul_keep_hierarchy.argtypes = [vp, i32]
         L.emul_keep_hierarchy.restype = None
         L.emul_hierarchy_reused.argtypes = [vp]
+        L.emul_work_plane.argtypes = [vp, vp]
+        L.emul_work_plane.restype = None
         _lib = L
     return _lib
 
@@ -190,6 +192,11 @@ class Scene:
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_inst": inst, "hit_tri": tri, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(),
                 "tlas_pairs": pairs.value, "tlas_depth": depth.value}
+
+    def record_work(self, plane):
+        """plane: uint32 array [h, w, 2] that instanced frames fill with each pixel's {box tests, triangle tests}; None stops it.
+        The caller keeps the array alive while frames are rendered."""
+        lib().emul_work_plane(self.h, plane.ctypes.data if plane is not None else None)
 
     def keep_hierarchy(self, on: bool):
         """Instanced frames from now on keep the hierarchy over the instances between calls, as the product does."""

@@ -40,6 +40,7 @@ struct EmulScene {
     int stack_high = 0;
     bool regroup = false;
     bool keep_hierarchy = false;       // instanced frames: the product's hierarchy kept from call to call
+    uint32_t* work_plane = nullptr;    // instanced frames: per pixel {box tests, triangle tests} of both rays, when set
     StandingTlas standing;
     int hierarchy_reused = 0;          // calls that reused the kept tree
 };
@@ -225,6 +226,10 @@ int emul_render_sampled(void* sp, const rt_camera* cam, const rt_light* lights, 
     return RT_OK;
 }
 
+// Instanced frames rendered after this call also record, per pixel, the box and triangle tests of its two rays
+// ({boxes, triangles} as uint32 pairs, row-major); a null pointer stops the recording.
+void emul_work_plane(void* sp, uint32_t* per_pixel) { ((EmulScene*)sp)->work_plane = per_pixel; }
+
 // The product's instanced pixel (rt_instanced.h) with the product's instance hierarchy (rt_pack.h).
 int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light, const int32_t* mesh_ids, const rt_transform* tfs, int32_t n_inst,
                           int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_inst, int32_t* hit_tri, float* hit_t, uint8_t* shadow,
@@ -273,6 +278,7 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
             if (hit_t) hit_t[p] = r.hit_t;
             if (shadow) shadow[p] = r.shadow;
             c_slab += w.slabs; c_tri += w.tris; c_hit += r.hit; c_dark += r.dark;
+            if (s->work_plane) { s->work_plane[p * 2] = w.slabs; s->work_plane[p * 2 + 1] = w.tris; }
         }
     }
     if (counters) {
