@@ -65,6 +65,9 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--verbose", action="store_true", help="phase markers on stderr")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    p.add_argument("--collective-at-one-rank", action="store_true",
+                   help="one rank started under torch.distributed.run: create the process group and gather through it all the same "
+                        "(the backend's calls on a one-GPU machine)")
     p.add_argument("--one-device", action="store_true",
                    help="rehearsal on a one-GPU machine: every rank uses GPU 0 (use with --backend gloo)")
     p.add_argument("--rehearse-cpu", action="store_true",
@@ -182,7 +185,8 @@ def main():
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    grouped = world > 1 or (a.collective_at_one_rank and "WORLD_SIZE" in os.environ)
+    if grouped:
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -253,18 +257,18 @@ def main():
             scene.render_frames(batches[k % nb], W, H, bufs[k % len(bufs)], stream=sptr)
     for k, i in enumerate(range(0, a.warmup, a.batch)):
         scene.render_frames(warm[i:min(i + a.batch, a.warmup)], W, H, bufs[k % len(bufs)], stream=sptr)
-    if world > 1:
-        g = sharding.FrameGather(rank, world)
+    if grouped:
+        g = sharding.FrameGather(rank, world, collective_at_one_rank=grouped)
         g.submit(bufs[0])
         g.finish()
     device_sync()
     say("warm-up rendered and gathered")
-    if world > 1:
+    if grouped:
         dist.barrier()
 
     # ---- timed region: exactly `steps` frames
     # rank 0 drops the gathered frames (an encoder would consume them here)
-    gather = sharding.FrameGather(rank, world, ring=RING - 1) if world > 1 else None
+    gather = sharding.FrameGather(rank, world, ring=RING - 1, collective_at_one_rank=grouped) if grouped else None
     if gather is not None:
         gather.prealloc(nb, bufs[0])
         dist.barrier()
@@ -277,13 +281,13 @@ def main():
     if gather is not None:
         gather.finish()
     device_sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
     say(f"timed region done in {dt:.4f} s")
 
     rays_rank = sum(info[f]["primary_rays"] + info[f]["shadow_rays"] for f in seq)
-    if world > 1:
+    if grouped:
         stats = torch.tensor([dt, float(rays_rank)], dtype=torch.float64, device=dev)
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -299,13 +303,13 @@ def main():
     # ---- untimed: what arrives on rank 0 is what the ranks rendered.  Every rank sends the first batch of its
     # timed steps once more; rank 0 renders the same frames itself and compares the bytes.
     gather_ok = None
-    if world > 1:
+    if grouped:
         def first_batch(r):
             sh = sharding.frames_for_rank(NF, r, world) or [r % NF]
             fr = frame_sequence(sh, a.batch)
             return fr
         scene.render_frames(first_batch(rank), W, H, bufs[0], stream=sptr)
-        g = sharding.FrameGather(rank, world)
+        g = sharding.FrameGather(rank, world, collective_at_one_rank=grouped)
         g.submit(bufs[0])
         got = g.finish()
         device_sync()
@@ -401,9 +405,9 @@ def main():
                                  "an even sample of the animation for any --steps",
                        "frames_per_rank": a.steps, "frames_per_launch": a.batch, "untimed_settling_launches": SETTLE,
                        "sharding": "frame f on rank f mod N" if world > 1 else "single GPU",
-                       "gather": f"RGB8 framebuffers to rank 0 over {transport}, {a.batch} frames per message" if world > 1 else "none",
-                       "world_size": dist.get_world_size() if world > 1 else 1,
-                       "backend": (dist.get_backend() if world > 1 else None),
+                       "gather": f"RGB8 framebuffers to rank 0 over {transport}, {a.batch} frames per message" if grouped else "none",
+                       "world_size": dist.get_world_size() if grouped else 1,
+                       "backend": (dist.get_backend() if grouped else None),
                        "rank_devices": rank_devices,
                        "gathered_frames_equal_rank0_render": gather_ok},
             "frames_per_s": round(a.steps * world / dt_all, 2),
@@ -418,7 +422,7 @@ def main():
             out["data"] = "byte patterns"
         print(json.dumps(out), flush=True)
     scene.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

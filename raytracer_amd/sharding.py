@@ -40,8 +40,11 @@ class FrameGather:
     """
 
     def __init__(self, rank: int, world: int, group=None, ring: Optional[int] = None,
-                 consume: Optional[Callable[[int, List[torch.Tensor]], None]] = None):
+                 consume: Optional[Callable[[int, List[torch.Tensor]], None]] = None, collective_at_one_rank: bool = False):
         self.rank, self.world, self.group = rank, world, group
+        # a single rank needs no transfer; with this set it issues the collective all the same (a one-rank process group must
+        # exist): the way to run the backend's gather on a machine with one GPU
+        self.solo = world == 1 and not collective_at_one_rank
         self.ring, self.consume = ring, consume
         self._pending = []      # (sequence number, work, recv_list or None)
         self._pool = []         # receive lists ready for reuse (rank 0)
@@ -50,7 +53,7 @@ class FrameGather:
     def prealloc(self, n_submits: int, like: torch.Tensor):
         """Allocates rank 0's receive buffers for the next n_submits calls (or for the whole ring) up
         front, so that no device allocation happens between submit() calls."""
-        if self.rank == 0 and self.world > 1:
+        if self.rank == 0 and not self.solo:
             n = min(n_submits, self.ring) if self.ring else n_submits
             self._pool = [[torch.empty_like(like) for _ in range(self.world)] for _ in range(n)]
 
@@ -61,7 +64,7 @@ class FrameGather:
         if self.rank == 0 and recv is not None:
             if self.consume is not None:
                 self.consume(seq, recv)
-            if self.world > 1:
+            if not self.solo:
                 self._pool.append(recv)
 
     def submit(self, batch: torch.Tensor):
@@ -69,7 +72,7 @@ class FrameGather:
             self._retire_oldest()
         seq = self._seq
         self._seq += 1
-        if self.world == 1:
+        if self.solo:
             self._pending.append((seq, None, [batch]))
             return
         if batch.is_cuda and dist.get_backend(self.group) == "gloo":

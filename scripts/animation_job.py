@@ -34,6 +34,8 @@ def parse(argv):
     p.add_argument("--backend", default="nccl")
     p.add_argument("--one-device", action="store_true", help="rehearsal: every rank on GPU 0 (with --backend gloo)")
     p.add_argument("--master-port", type=int, default=0)
+    p.add_argument("--collective-at-one-rank", action="store_true",
+                   help="started under torch.distributed.run with one rank: create the process group and gather through it all the same")
     return p.parse_args(argv)
 
 
@@ -52,7 +54,8 @@ def main():
         sys.exit("animation_job.py: no GPU visible; the rendering core has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    grouped = world > 1 or (a.collective_at_one_rank and "WORLD_SIZE" in os.environ)
+    if grouped:
         dist.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
     scene = demo.DemoScene(local)
     ctx = scene.ctx
@@ -92,9 +95,9 @@ def main():
     # one untimed launch: code objects and clocks
     scene.render_frames([mine[0] if mine else 0], W, H, bufs[0][:1], stream=stream.cuda_stream)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if grouped:
         dist.barrier()
-    gather = sharding.FrameGather(rank, world, ring=3, consume=consume)
+    gather = sharding.FrameGather(rank, world, ring=3, consume=consume, collective_at_one_rank=grouped)
     gather.prealloc(n_batches, bufs[0])
     t0 = time.perf_counter()
     for b in range(n_batches):
@@ -108,18 +111,18 @@ def main():
     if sink is not None:
         sink.close()
     t_all = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         dist.barrier()
     if rank == 0:
         print(json.dumps({"job": "the reference driver's animation, frame f on rank f mod N, framebuffers gathered to rank 0",
-                          "frames": seen[0], "width": W, "height": H, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None,
+                          "frames": seen[0], "width": W, "height": H, "n_gpus": world, "backend": dist.get_backend() if grouped else None,
                           "frames_per_launch": B, "seconds_until_all_frames_on_rank0": round(t_frames, 4),
                           "seconds_until_file_closed": round(t_all, 4) if sink is not None else None,
                           "frames_per_s": round(seen[0] / t_frames, 1), "all_frames_sha256": sha.hexdigest() if hashing else None,
                           "equals_compiled_reference": (sha.hexdigest() == gold) if gold else None,
                           "file": a.out or None}), flush=True)
     scene.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -120,3 +120,36 @@ def test_the_animation_job_over_two_ranks_gathers_the_same_frames():
     """Two ranks on the one GPU, frames gathered through gloo: rank 0 ends up with the same 96 frames in order."""
     got = _animation_job("--gpus", "2", "--backend", "gloo", "--one-device")
     assert got["n_gpus"] == 2 and got["frames"] == 96 and got["equals_compiled_reference"] is True
+
+
+@pytest.mark.gpu
+def test_the_animation_job_through_rccl_with_a_single_rank():
+    """One rank under torch.distributed.run with the nccl backend: the process group is RCCL's and every batch goes through its
+    gather (to itself).  What a one-GPU machine can show of the path N GPUs take."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                           "--master-port", "29731", os.path.join(repo, "scripts", "animation_job.py"), "--backend", "nccl",
+                           "--collective-at-one-rank"], capture_output=True, text=True, timeout=300, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    got = [json.loads(ln) for ln in proc.stdout.splitlines() if ln.startswith("{") and '"job"' in ln]
+    assert len(got) == 1 and got[0]["backend"] == "nccl" and got[0]["frames"] == 96 and got[0]["equals_compiled_reference"] is True
+
+
+@pytest.mark.gpu
+def test_bench_through_rccl_with_a_single_rank():
+    """bench.py as one rank of an RCCL process group: the gathers of the timed region and the gathered-bytes check run through
+    RCCL's gather."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                           "--master-port", "29733", os.path.join(repo, "bench.py"), "--collective-at-one-rank", "--steps", "16", "--warmup", "8",
+                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["backend"] == "nccl" and out["config"]["world_size"] == 1
+    assert out["config"]["gathered_frames_equal_rank0_render"] is True and out["value"] > 0

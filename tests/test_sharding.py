@@ -258,6 +258,21 @@ def test_bench_starts_its_own_ranks_when_given_a_gpu_count():
     assert "rehearsal" in out and out["steps"] == 8 and out["scaling"] == "weak"
 
 
+def test_bench_single_rank_can_go_through_the_process_group():
+    """One rank under torch.distributed.run with --collective-at-one-rank: the process group exists and every batch is gathered
+    through it (here gloo on byte patterns; on a GPU machine the same switch runs RCCL's gather with one GPU)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29741", os.path.join(REPO, "bench.py"), "--rehearse-cpu", "--collective-at-one-rank", "--steps", "8",
+                        "--warmup", "2", "--width", "64", "--height", "36", "--batch", "4"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["config"]["world_size"] == 1 and out["config"]["backend"] == "gloo"
+    assert out["config"]["gathered_frames_equal_rank0_render"] is True
+
+
 def test_bench_parent_fails_when_a_rank_fails():
     """Without a GPU the ranks refuse to run (there is no CPU rendering path); the parent must not exit 0."""
     if torch.cuda.is_available():
