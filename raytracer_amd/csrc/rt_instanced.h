@@ -22,39 +22,53 @@ struct InstancedOut {
     uint32_t hit, dark;
 };
 
-// World-space walk over the instance hierarchy; calls visit(instance index) for every instance whose
-// padded box the ray enters no farther than limit().  visit returns true to stop the walk.
-template <class TStack, class Visit, class Limit>
-RT_HD void walk_instances(const InstancedArgs& I, F3 o, F3 inv, TStack& ts, Limit limit, Visit visit) {
-    float entry;
-    if (I.n_inst <= 0 || !slab_t(o, inv, I.root_min, I.root_max, entry)) return;
-    const SlabRay sr = slab_ray(o, inv);
-    ts.clear();
-    uint32_t ref = I.tlas_root;
-    bool live = true;
-    while (live) {
-        while (live && !(ref & kLeafBit)) {
-            const PairNode N = I.tlas[ref];
-            float tl, tr;
-            bool hl, hr;
-            slab_pair(sr, N, tl, tr, hl, hr);
-            const float lim = limit();
-            hl = hl && !(tl > lim); hr = hr && !(tr > lim);
-            const bool left_first = !(tr < tl);
-            if (hl && hr) { ts.push(left_first ? N.rref : N.lref); ref = left_first ? N.lref : N.rref; }
-            else if (hl || hr) ref = hl ? N.lref : N.rref;
-            else if (ts.empty()) live = false;
-            else ref = ts.pop();
-        }
-        if (live) {
-            const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
-            for (uint32_t k = 0; k < count; k++)
-                if (visit(I.order[first + k])) return;
-            if (ts.empty()) live = false;
-            else ref = ts.pop();
-        }
+// World-space walk over the instance hierarchy, one instance at a time.  next() goes on until it reaches an instance whose
+// padded box the ray enters no farther than limit() AND that accept(instance index) takes (the caller's exact test in the
+// instance's own space); it returns that index, or -1 when the hierarchy is used up.  The caller then walks the instance.
+// Written like this the lanes of a wave look for their next instance together and walk together: a lane whose proposal
+// fails the exact test goes on searching at once instead of sitting out the others' walk.
+template <class TStack>
+struct InstanceWalk {
+    SlabRay sr;
+    uint32_t ref;
+    bool live;
+    RT_HD void begin(const InstancedArgs& I, F3 o, F3 inv, TStack& ts) {
+        float entry;
+        live = I.n_inst > 0 && slab_t(o, inv, I.root_min, I.root_max, entry);
+        sr = slab_ray(o, inv);
+        ts.clear();
+        ref = I.tlas_root;
     }
-}
+    template <class Limit, class Accept>
+    RT_HD int next(const InstancedArgs& I, TStack& ts, Limit limit, Accept accept) {
+        while (live) {
+            while (live && !(ref & kLeafBit)) {
+                const PairNode N = I.tlas[ref];
+                float tl, tr;
+                bool hl, hr;
+                slab_pair(sr, N, tl, tr, hl, hr);
+                const float lim = limit();
+                hl = hl && !(tl > lim); hr = hr && !(tr > lim);
+                const bool left_first = !(tr < tl);
+                if (hl && hr) { ts.push(left_first ? N.rref : N.lref); ref = left_first ? N.lref : N.rref; }
+                else if (hl || hr) ref = hl ? N.lref : N.rref;
+                else if (ts.empty()) live = false;
+                else ref = ts.pop();
+            }
+            if (live) {
+                const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
+                if (count > 1) ref = leaf_ref(first + 1, count - 1);          // the rest of this leaf comes next
+                else if (ts.empty()) live = false;
+                else ref = ts.pop();
+                if (count > 0) {
+                    const uint32_t i = I.order[first];
+                    if (accept(i)) return (int)i;
+                }
+            }
+        }
+        return -1;
+    }
+};
 
 template <bool COUNT, class Stack, class TStack, class Nodes, class Party>
 RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs& I, const Nodes& nodes, const Party& party, int px, int py,
@@ -72,19 +86,29 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
     float closest = 1e30f;
     int who = -1;
     Hit best = no_hit();
-    walk_instances(I, wo, recip(wd), tstack, [&]() { return cull_limit(closest); }, [&](uint32_t i) {
+    InstanceWalk<TStack> walk;
+    walk.begin(I, wo, recip(wd), tstack);
+    for (;;) {
+        F3 ld = f3(0.0f, 0.0f, 0.0f), linv = ld;
+        const int i = walk.next(I, tstack, [&]() { return cull_limit(closest); }, [&](uint32_t k) {
+            const MeshArgs& M = I.inst[k];
+            ld = unit(xform_vector<4>(M.inv, wd));                                               // ray.c:20,22
+            linv = recip(ld);
+            // what begin_query decides (bvh.c:82 at the root, and the distance the closest hit so far allows); a mesh that is
+            // a single leaf honours the bound inside the leaf (bvh.c:85): it gets none, the comparison below decides
+            float entry;
+            if (!slab_t(f3(M.cam_o), linv, M.root_min, M.root_max, entry) || M.empty) return false;
+            return !(entry > cull_limit((M.root_ref & kLeafBit) ? 1e30f : closest));
+        });
+        if (i < 0) break;
         const MeshArgs& M = I.inst[i];
-        const F3 ld = unit(xform_vector<4>(M.inv, wd));
         Hit h = no_hit();
-        // a mesh that is a single leaf honours the bound inside the leaf (bvh.c:85): give it none, the
-        // comparison below decides
         const float bound = (M.root_ref & kLeafBit) ? 1e30f : closest;
-        if (party.template closest<COUNT, false>(M, nodes, f3(M.cam_o), ld, recip(ld), bound, h, stack, work) &&
-            (h.t < closest || (h.t == closest && (int)i < who))) {
-            closest = h.t; who = (int)i; best = h;
+        if (party.template closest<COUNT, false>(M, nodes, f3(M.cam_o), ld, linv, bound, h, stack, work) &&
+            (h.t < closest || (h.t == closest && i < who))) {
+            closest = h.t; who = i; best = h;
         }
-        return false;
-    });
+    }
     out.hit_t = closest;
     if (who < 0) {
         out.r = out.g = out.b = 50; out.shadow = 255; out.inst = -1; out.tri = -1; out.hit = 0; out.dark = 0;
@@ -94,7 +118,7 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
     out.hit = 1; out.inst = who; out.tri = (int32_t)best.tri;
 
     // ---- attributes, texel (scene.c:86-106, mesh.c:138-149) ----
-    const AttrRec& R = M.attrs[best.tri];
+    const AttrRec R = read_attrs(M.attrs, best.tri);
     const float u = best.u, v = best.v;
     const float w = 1.0f - u - v;
     const float tu = w * R.t0[0] + u * R.t1[0] + v * R.t2[0];
@@ -104,19 +128,26 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
     const float su = tu - floorf(tu), sv = tv - floorf(tv);
     const int tx = (int)(su * (float)(M.tex_w - 1));
     const int ty = (int)(sv * (float)(M.tex_h - 1));
-    const uint32_t texel = M.texels[ty * M.tex_w + tx];
+    const uint32_t texel = read_word(M.texels, (size_t)(ty * M.tex_w + tx));
     F3 color = f3((float)(texel & 0xFFu) / 255.0f, (float)((texel >> 8) & 0xFFu) / 255.0f, (float)((texel >> 16) & 0xFFu) / 255.0f);
 
     // ---- shadow ray (scene.c:117-139): any instance ----
     const F3 so = add(add(wo, scale(wd, closest)), scale(n, 0.001f));
     const F3 L = f3(A.light_dir);
     bool dark = false;
-    walk_instances(I, so, recip(L), tstack, []() { return 3.0e38f; }, [&](uint32_t i) {
+    walk.begin(I, so, recip(L), tstack);
+    while (!dark) {
+        F3 lo = so;
+        const int i = walk.next(I, tstack, []() { return 3.0e38f; }, [&](uint32_t k) {
+            const MeshArgs& S = I.inst[k];
+            lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);     // ray.c:19
+            float entry;
+            return slab_t(lo, f3(S.lit_inv), S.root_min, S.root_max, entry) && !S.empty;         // bvh.c:82 at the root
+        });
+        if (i < 0) break;
         const MeshArgs& S = I.inst[i];
-        const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);
         dark = party.template any<COUNT, false>(S, nodes, lo, f3(S.lit_d), f3(S.lit_inv), stack, work);
-        return dark;
-    });
+    }
     float diffuse = 0.2f;
     if (!dark) diffuse = fmaxf(diffuse, dot(n, L));
     color = scale(mul(color, f3(A.light_color)), diffuse);

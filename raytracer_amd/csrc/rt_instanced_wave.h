@@ -115,7 +115,7 @@ __device__ __forceinline__ void step_leaf(WaveLane<BLOCK>& L) {
         TriRec T[kLeafBatch];
         const uint32_t n = count - i0 < kLeafBatch ? count - i0 : kLeafBatch;
         RT_UNROLL
-        for (uint32_t k = 0; k < kLeafBatch; k++) T[k] = L.tris[first + i0 + (k < n ? k : 0)];
+        for (uint32_t k = 0; k < kLeafBatch; k++) T[k] = read_tri(L.tris, first + i0 + (k < n ? k : 0));
         RT_UNROLL
         for (uint32_t k = 0; k < kLeafBatch; k++) {
             if (k >= n || stop) continue;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void step_shade(WaveLane<BLOCK>& L, const FrameArgs& 
     L.shadow_mode = true;
     if (L.who < 0) { L.ref = kRefEnd; return; }
     const MeshArgs& M = I.inst[L.who];
-    const AttrRec& R = M.attrs[L.btri];
+    const AttrRec R = read_attrs(M.attrs, L.btri);
     const float u = L.bu, v = L.bv;
     const float w = 1.0f - u - v;
     const float tu = w * R.t0[0] + u * R.t1[0] + v * R.t2[0];
@@ -188,7 +188,7 @@ __device__ __forceinline__ void step_shade(WaveLane<BLOCK>& L, const FrameArgs& 
     const float su = tu - floorf(tu), sv = tv - floorf(tv);                                       // mesh.c:138-149
     const int tx = (int)(su * (float)(M.tex_w - 1));
     const int ty = (int)(sv * (float)(M.tex_h - 1));
-    const uint32_t texel = M.texels[ty * M.tex_w + tx];
+    const uint32_t texel = read_word(M.texels, (size_t)(ty * M.tex_w + tx));
     const F3 tex = f3((float)(texel & 0xFFu) / 255.0f, (float)((texel >> 8) & 0xFFu) / 255.0f, (float)((texel >> 16) & 0xFFu) / 255.0f);
     L.color = mul(tex, f3(A.light_color));                                                        // scene.c:148
     const F3 lightdir = f3(A.light_dir);

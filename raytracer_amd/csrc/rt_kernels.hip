@@ -35,7 +35,7 @@ namespace rt {
 struct LdsNodes {
     const PairNode* all;
     __device__ __forceinline__ const PairNode& operator()(const MeshArgs& M, uint32_t ref) const { return all[M.pair_base + ref]; }
-    __device__ __forceinline__ const TriRec& tri(const MeshArgs& M, uint32_t index) const { return M.tris[index]; }
+    __device__ __forceinline__ TriRec tri(const MeshArgs& M, uint32_t index) const { return read_tri(M.tris, index); }
 };
 
 // Pixel of (tile, lane): a wave owns an 8x8 tile, lanes row-major inside it, so the rays of a
@@ -425,7 +425,7 @@ struct HybridNodes {
     }
     __device__ __forceinline__ TriRec tri(const MeshArgs& M, uint32_t index) const {
         if (M.res_tris != kNotResident) return *reinterpret_cast<const TriRec*>(lds + M.res_tris + (size_t)index * sizeof(TriRec));
-        return M.tris[index];
+        return read_tri(M.tris, index);
     }
 };
 

@@ -38,12 +38,52 @@ struct Work {
     uint32_t slabs, tris;
 };
 
+// Reads through the pointers a MeshArgs carries (triangles, attributes, texels, grid cells).  Device code reads such a
+// pointer from memory first, so the compiler cannot know which memory it points to and would use FLAT accesses; those
+// count against both of a wave's memory counters, and every wait for an LDS read (the traversal stack) would then wait
+// for them as well.  The arrays live in global memory: the device build says so.  Host build: plain reads.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_GLOBAL_AS __attribute__((address_space(1)))
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class V>
+__device__ __forceinline__ V global_read(const void* base, size_t byte_offset) {
+    return *(const RT_GLOBAL_AS V*)((const RT_GLOBAL_AS char*)base + byte_offset);
+}
+__device__ __forceinline__ TriRec read_tri(const TriRec* tris, uint32_t index) {
+    const size_t at = (size_t)index * sizeof(TriRec);
+    const f32x4 a = global_read<f32x4>(tris, at);
+    const f32x3 b = global_read<f32x3>(tris, at + 16), c = global_read<f32x3>(tris, at + 32);
+    TriRec t;
+    t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.prio = __float_as_uint(a.w);
+    t.e1[0] = b.x; t.e1[1] = b.y; t.e1[2] = b.z; t.pad1 = 0.0f;
+    t.e2[0] = c.x; t.e2[1] = c.y; t.e2[2] = c.z; t.pad2 = 0.0f;
+    return t;
+}
+__device__ __forceinline__ AttrRec read_attrs(const AttrRec* attrs, uint32_t index) {
+    const size_t at = (size_t)index * sizeof(AttrRec);
+    const f32x4 a = global_read<f32x4>(attrs, at), b = global_read<f32x4>(attrs, at + 16), c = global_read<f32x4>(attrs, at + 32);
+    const f32x3 d = global_read<f32x3>(attrs, at + 48);
+    AttrRec r;
+    r.t0[0] = a.x; r.t0[1] = a.y; r.t1[0] = a.z; r.t1[1] = a.w; r.t2[0] = b.x; r.t2[1] = b.y;
+    r.n0[0] = b.z; r.n0[1] = b.w; r.n0[2] = c.x; r.n1[0] = c.y; r.n1[1] = c.z; r.n1[2] = c.w;
+    r.n2[0] = d.x; r.n2[1] = d.y; r.n2[2] = d.z; r.pad = 0.0f;
+    return r;
+}
+__device__ __forceinline__ uint32_t read_word(const uint32_t* words, size_t index) { return global_read<uint32_t>(words, index * 4); }
+#else
+RT_HD TriRec read_tri(const TriRec* tris, uint32_t index) { return tris[index]; }
+RT_HD AttrRec read_attrs(const AttrRec* attrs, uint32_t index) { return attrs[index]; }
+RT_HD uint32_t read_word(const uint32_t* words, size_t index) { return words[index]; }
+#endif
+
 // Node source: where PairNodes are read from.  GlobalNodes reads the scene's combined node array
 // through the vector cache; the kernels also have a source that reads a copy staged in LDS.
 struct GlobalNodes {
     const PairNode* all;
     RT_HD const PairNode& operator()(const MeshArgs& M, uint32_t ref) const { return all[M.pair_base + ref]; }
-    RT_HD const TriRec& tri(const MeshArgs& M, uint32_t index) const { return M.tris[index]; }
+    RT_HD TriRec tri(const MeshArgs& M, uint32_t index) const { return read_tri(M.tris, index); }
 };
 
 // Distance culling (used unless the caller asks for the reference's visiting order).
@@ -210,7 +250,7 @@ RT_HD uint32_t grid_entry(const MeshArgs& M, F3 o, F3 d, F3 inv, uint32_t root) 
     const float n = (float)M.grid_n;
     // every comparison is false for a NaN, so a ray whose numbers overflow keeps the root
     if (!(ea <= M.grid_slack[0] && eb <= M.grid_slack[1] && fa >= 0.0f && fa < n && fb >= 0.0f && fb < n)) return root;
-    return M.grid[(uint32_t)(int)fb * (uint32_t)M.grid_n + (uint32_t)(int)fa];
+    return read_word(M.grid, (size_t)((uint32_t)(int)fb * (uint32_t)M.grid_n + (uint32_t)(int)fa));
 }
 
 // Closest hit (ANY=false) or any hit (ANY=true) of one mesh by ONE lane, ray already in mesh space.
@@ -379,7 +419,7 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     out.hit_id = (int32_t)(((uint32_t)who << 24) | best.tri);
 
     // ---- attributes of the winning hit (scene.c:86-106) ----
-    const AttrRec& R = M.attrs[best.tri];
+    const AttrRec R = read_attrs(M.attrs, best.tri);
     const float u = best.u, v = best.v;
     const float w = 1.0f - u - v;
     const float tu = w * R.t0[0] + u * R.t1[0] + v * R.t2[0];
@@ -391,7 +431,7 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     const float su = tu - floorf(tu), sv = tv - floorf(tv);
     const int tx = (int)(su * (float)(M.tex_w - 1));
     const int ty = (int)(sv * (float)(M.tex_h - 1));
-    const uint32_t texel = M.texels[ty * M.tex_w + tx];
+    const uint32_t texel = read_word(M.texels, (size_t)(ty * M.tex_w + tx));
     F3 color = f3((float)(texel & 0xFFu) / 255.0f, (float)((texel >> 8) & 0xFFu) / 255.0f,
                   (float)((texel >> 16) & 0xFFu) / 255.0f);
 

@@ -79,7 +79,7 @@ RT_HD F3 sample_value(const FrameArgs& A, const SampleArgs& X, const Nodes& node
         out.hits++;
         if (s == 0) out.hit_id = (int32_t)(((uint32_t)who << 24) | best.tri);
         // ---- attributes and texel of the hit (scene.c:86-106, mesh.c:138-149) ----
-        const AttrRec& R = M.attrs[best.tri];
+        const AttrRec R = read_attrs(M.attrs, best.tri);
         const float u = best.u, v = best.v;
         const float w = 1.0f - u - v;
         const float tu = w * R.t0[0] + u * R.t1[0] + v * R.t2[0];
@@ -89,7 +89,7 @@ RT_HD F3 sample_value(const FrameArgs& A, const SampleArgs& X, const Nodes& node
         const float su = tu - floorf(tu), sv = tv - floorf(tv);
         const int tx = (int)(su * (float)(M.tex_w - 1));
         const int ty = (int)(sv * (float)(M.tex_h - 1));
-        const uint32_t texel = M.texels[ty * M.tex_w + tx];
+        const uint32_t texel = read_word(M.texels, (size_t)(ty * M.tex_w + tx));
         const F3 tex = f3((float)(texel & 0xFFu) / 255.0f, (float)((texel >> 8) & 0xFFu) / 255.0f,
                           (float)((texel >> 16) & 0xFFu) / 255.0f);
         // ---- one shadow ray per light (scene.c:117-149) ----
