@@ -96,7 +96,7 @@ struct rt_ctx {
     int coop = 1;                  // cooperative rendering of the big meshes' screen area (variant 3)
     // rt_render_frames: per-frame constants travel through a ring of staging slots (pinned host
     // copy -> device copy on the caller's stream); a slot is reused once its event has completed.
-    // rt_render_frame_instanced: per call [MeshArgs x n][PairNode x n][order x n] staged through one of
+    // rt_render_frame_instanced: per call [MeshArgs x n][PairNode x (2n + 2)] staged through one of
     // two slots (pinned host copy -> device copy on the caller's stream)
     uint8_t* h_inst[kInstSlots] = {};
     uint8_t* d_inst[kInstSlots] = {};
@@ -951,8 +951,7 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
     if (ctx->inst_used[slot]) RT_HIP(ctx, hipEventSynchronize(ctx->inst_done[slot]));
     const size_t n = (size_t)(n_instances > 0 ? n_instances : 1);
     // a kept hierarchy that was patched holds its old leaves too: room for twice the instances
-    const size_t off_pairs = (n * sizeof(MeshArgs) + 63) & ~(size_t)63, off_order = off_pairs + (2 * n + 2) * sizeof(PairNode),
-                 total = off_order + (((2 * n + 2) * sizeof(uint32_t) + 63) & ~(size_t)63);
+    const size_t off_pairs = (n * sizeof(MeshArgs) + 63) & ~(size_t)63, total = off_pairs + (2 * n + 2) * sizeof(PairNode);
     if (n > ctx->inst_capacity[slot]) {
         if (ctx->h_inst[slot]) (void)hipHostFree(ctx->h_inst[slot]);
         if (ctx->d_inst[slot]) (void)hipFree(ctx->d_inst[slot]);
@@ -997,17 +996,15 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
     if (ctx->keep_hierarchy) (void)ctx->standing.update(boxes, ids, (size_t)n_instances, T);
     else TlasBuilder(boxes, ids, T).run();
     if (T.depth + 2 > kTlasStackDepth) return fail(ctx, RT_ERR_UNSUPPORTED, "instance hierarchy deeper than its stack");
-    if (T.pairs.size() > 2 * n + 2 || T.order.size() > 2 * n + 2) return fail(ctx, RT_ERR_DEVICE, "instance hierarchy larger than its staging area");
-    if (!T.pairs.empty()) memcpy(h + off_pairs, T.pairs.data(), T.pairs.size() * sizeof(PairNode));
-    if (!T.order.empty()) memcpy(h + off_order, T.order.data(), T.order.size() * sizeof(uint32_t));
+    if (T.pairs.size() > 2 * n + 2) return fail(ctx, RT_ERR_DEVICE, "instance hierarchy larger than its staging area");
+    write_direct(T, reinterpret_cast<PairNode*>(h + off_pairs));
     RT_HIP(ctx, hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
 
     InstancedArgs I;
     I.inst = reinterpret_cast<const MeshArgs*>(d);
     I.n_inst = (int32_t)ids.size();
-    I.tlas_root = T.root_ref;
+    I.tlas_root = direct_ref(T, T.root_ref);
     I.tlas = reinterpret_cast<const PairNode*>(d + off_pairs);
-    I.order = reinterpret_cast<const uint32_t*>(d + off_order);
     memcpy(I.root_min, T.root_min, 12); memcpy(I.root_max, T.root_max, 12);
     OutputPlanes O;
     O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_instance; O.hit_t = (float*)d_hit_t; O.shadow = (uint8_t*)d_shadow;

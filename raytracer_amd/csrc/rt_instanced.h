@@ -56,19 +56,27 @@ struct InstanceWalk {
                 else ref = ts.pop();
             }
             if (live) {
-                const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
-                if (count > 1) ref = leaf_ref(first + 1, count - 1);          // the rest of this leaf comes next
-                else if (ts.empty()) live = false;
+                const uint32_t i = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;      // the leaf names its instance
+                if (ts.empty()) live = false;
                 else ref = ts.pop();
-                if (count > 0) {
-                    const uint32_t i = I.order[first];
-                    if (accept(i)) return (int)i;
-                }
+                if (count > 0 && accept(i)) return (int)i;
             }
         }
         return -1;
     }
 };
+
+// The fields of an instance's MeshArgs that a walk through its tree reads (begin_query, entry_ref, the node and triangle
+// sources), copied to a record the caller keeps in registers.  The flat-mesh grid is left out (grid_axis = 3: none): its
+// nine fields would have to ride along for every instance, and the instances that are not flat pay for them.
+RT_HD void take_walk_fields(const MeshArgs& M, MeshArgs& W) {
+    W.pair_base = M.pair_base; W.tris = M.tris;
+    W.root_min[0] = M.root_min[0]; W.root_min[1] = M.root_min[1]; W.root_min[2] = M.root_min[2];
+    W.root_max[0] = M.root_max[0]; W.root_max[1] = M.root_max[1]; W.root_max[2] = M.root_max[2];
+    W.root_ref = M.root_ref; W.ref_root = M.ref_root; W.empty = M.empty;
+    W.res_pairs = kNotResident; W.res_tris = kNotResident;
+    W.grid = nullptr; W.grid_axis = 3u;
+}
 
 template <bool COUNT, class Stack, class TStack, class Nodes, class Party>
 RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs& I, const Nodes& nodes, const Party& party, int px, int py,
@@ -89,22 +97,27 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
     InstanceWalk<TStack> walk;
     walk.begin(I, wo, recip(wd), tstack);
     for (;;) {
-        F3 ld = f3(0.0f, 0.0f, 0.0f), linv = ld;
+        // What the walk inside an instance reads of its MeshArgs is taken over into registers in one go when the instance is
+        // proposed: read field by field where each is first needed, every one costs its own trip to memory, one after the
+        // other (instances differ from lane to lane, so these are vector loads of a record that is rarely in the L1).
+        MeshArgs W;
+        F3 ld = f3(0.0f, 0.0f, 0.0f), linv = ld, lo = ld;
         const int i = walk.next(I, tstack, [&]() { return cull_limit(closest); }, [&](uint32_t k) {
             const MeshArgs& M = I.inst[k];
+            take_walk_fields(M, W);
+            lo = f3(M.cam_o);
             ld = unit(xform_vector<4>(M.inv, wd));                                               // ray.c:20,22
             linv = recip(ld);
             // what begin_query decides (bvh.c:82 at the root, and the distance the closest hit so far allows); a mesh that is
             // a single leaf honours the bound inside the leaf (bvh.c:85): it gets none, the comparison below decides
             float entry;
-            if (!slab_t(f3(M.cam_o), linv, M.root_min, M.root_max, entry) || M.empty) return false;
-            return !(entry > cull_limit((M.root_ref & kLeafBit) ? 1e30f : closest));
+            if (!slab_t(lo, linv, W.root_min, W.root_max, entry) || W.empty) return false;
+            return !(entry > cull_limit((W.root_ref & kLeafBit) ? 1e30f : closest));
         });
         if (i < 0) break;
-        const MeshArgs& M = I.inst[i];
         Hit h = no_hit();
-        const float bound = (M.root_ref & kLeafBit) ? 1e30f : closest;
-        if (party.template closest<COUNT, false>(M, nodes, f3(M.cam_o), ld, linv, bound, h, stack, work) &&
+        const float bound = (W.root_ref & kLeafBit) ? 1e30f : closest;
+        if (party.template closest<COUNT, false>(W, nodes, lo, ld, linv, bound, h, stack, work) &&
             (h.t < closest || (h.t == closest && i < who))) {
             closest = h.t; who = i; best = h;
         }
@@ -137,16 +150,18 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
     bool dark = false;
     walk.begin(I, so, recip(L), tstack);
     while (!dark) {
-        F3 lo = so;
+        MeshArgs W;
+        F3 lo = so, sd = L, sinv = L;
         const int i = walk.next(I, tstack, []() { return 3.0e38f; }, [&](uint32_t k) {
             const MeshArgs& S = I.inst[k];
+            take_walk_fields(S, W);
+            sd = f3(S.lit_d); sinv = f3(S.lit_inv);
             lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);     // ray.c:19
             float entry;
-            return slab_t(lo, f3(S.lit_inv), S.root_min, S.root_max, entry) && !S.empty;         // bvh.c:82 at the root
+            return slab_t(lo, sinv, W.root_min, W.root_max, entry) && !W.empty;                  // bvh.c:82 at the root
         });
         if (i < 0) break;
-        const MeshArgs& S = I.inst[i];
-        dark = party.template any<COUNT, false>(S, nodes, lo, f3(S.lit_d), f3(S.lit_inv), stack, work);
+        dark = party.template any<COUNT, false>(W, nodes, lo, sd, sinv, stack, work);
     }
     float diffuse = 0.2f;
     if (!dark) diffuse = fmaxf(diffuse, dot(n, L));

@@ -144,10 +144,8 @@ __device__ __forceinline__ void step_switch(WaveLane<BLOCK>& L, const InstancedA
         L.ref = L.stack.pop();
         return;
     }
-    const uint32_t first = L.ref & 0x00FFFFFFu, count = (L.ref >> 24) & 0x7Fu;
-    if (count == 0) { L.ref = L.stack.pop(); return; }
-    if (count > 1) L.stack.push(leaf_ref(first + 1, count - 1));
-    const int i = (int)I.order[first];
+    const int i = (int)(L.ref & 0x00FFFFFFu);                                // the leaf names its instance
+    if (((L.ref >> 24) & 0x7Fu) == 0) { L.ref = L.stack.pop(); return; }
     const MeshArgs& M = I.inst[i];
     F3 o, d, inv;
     if (L.shadow_mode) {

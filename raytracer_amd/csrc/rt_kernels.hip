@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(64) render_instanced_wave(const FrameArgs A, c
 
 hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const SceneArgs& S, const OutputPlanes& O, int32_t* hit_tri,
                             int tlas_entries, int block, int wave_tiles, hipStream_t stream) {
-    if (A.width <= 0 || A.height <= 0 || !O.rgb || I.n_inst < 0 || (I.n_inst > 0 && (!I.inst || !I.order))) return hipErrorInvalidValue;
+    if (A.width <= 0 || A.height <= 0 || !O.rgb || I.n_inst < 0 || (I.n_inst > 0 && !I.inst)) return hipErrorInvalidValue;
     if (tlas_entries < 2 || tlas_entries > kTlasStackDepth || S.stack_entries < 2 || S.stack_entries > (uint32_t)kStackDepth) return hipErrorInvalidValue;
     const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
     if (count && !O.counters) return hipErrorInvalidValue;

@@ -148,7 +148,7 @@ struct SampleArgs {
 // Instanced scenes: any number of placed meshes (the reference's Scene.meshes may hold the same
 // triangles under many transforms, scene.c:31-35).  Every instance has a full MeshArgs in a device
 // array, in the scene's mesh order; a two-level hierarchy over the instances' world-space boxes
-// (same PairNode records; a leaf lists entries of `order`) only decides which instances a ray needs
+// (same PairNode records; a leaf is leaf_ref(instance index, 1), or leaf_ref(0, 0) for none) only decides which instances a ray needs
 // to be tested against -- the test itself is the reference's, in the instance's own space.
 constexpr int kTlasStackDepth = 32;
 struct InstancedArgs {
@@ -156,7 +156,6 @@ struct InstancedArgs {
     int32_t n_inst;
     uint32_t tlas_root;          // leaf ref or index of the root PairNode in `tlas`
     const PairNode* tlas;
-    const uint32_t* order;       // instance indices, grouped by hierarchy leaf
     float root_min[3], root_max[3];
 };
 

@@ -665,6 +665,23 @@ struct Tlas {
 
 constexpr size_t kTlasLeaf = 1;      // instances per leaf of the hierarchy
 
+// The hierarchy as the traversal reads it: every leaf names its instance itself, leaf_ref(instance index, 1), instead of a
+// position in `order` -- one dependent memory read less per proposed instance and ray.  (One instance per leaf; an emptied
+// leaf stays leaf_ref(0, 0).)
+inline uint32_t direct_ref(const Tlas& T, uint32_t ref) {
+    static_assert(kTlasLeaf == 1, "a leaf reference holds one instance index");
+    if (!(ref & kLeafBit)) return ref;
+    const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
+    return count ? leaf_ref(T.order[first], 1) : leaf_ref(0, 0);
+}
+inline void write_direct(const Tlas& T, PairNode* out) {
+    for (size_t i = 0; i < T.pairs.size(); i++) {
+        out[i] = T.pairs[i];
+        out[i].lref = direct_ref(T, T.pairs[i].lref);
+        out[i].rref = direct_ref(T, T.pairs[i].rref);
+    }
+}
+
 class TlasBuilder {
 public:
     // boxes[k] belongs to instance ids[k]; binned surface-area split of the centroids (median split along the

@@ -261,7 +261,9 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
     if (tlas_pairs) *tlas_pairs = (int32_t)T.pairs.size();
     if (tlas_depth) *tlas_depth = T.depth;
     InstancedArgs I;
-    I.inst = inst.data(); I.n_inst = (int32_t)ids.size(); I.tlas_root = T.root_ref; I.tlas = T.pairs.data(); I.order = T.order.data();
+    std::vector<PairNode> direct(T.pairs.size());
+    write_direct(T, direct.data());
+    I.inst = inst.data(); I.n_inst = (int32_t)ids.size(); I.tlas_root = direct_ref(T, T.root_ref); I.tlas = direct.data();
     memcpy(I.root_min, T.root_min, 12); memcpy(I.root_max, T.root_max, 12);
     GlobalNodes nodes; nodes.all = s->all_pairs.data();
     unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
