@@ -487,8 +487,14 @@ static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const Outp
 // Six waves per SIMD (80 registers, no spills) where the short stack leaves room in LDS: with meshes skipped per tile the
 // kernel waits for memory more than it did, and a sixth wave hides it (1.217 -> 1.158 ms per launch of 8 frames; seven
 // waves spill 40 bytes per lane and give the gain back, eight lose 20 %).
+// The fast build keeps six values more in registers (fused operands): at six waves it would spill, it runs five.
+#if defined(RT_FAST)
+constexpr int kBatchWaves = 5;
+#else
+constexpr int kBatchWaves = 6;
+#endif
 template <int BLOCK, int DEPTH, uint32_t LB>
-__global__ void __launch_bounds__(BLOCK, DEPTH <= 16 ? 6 : 5) render_batch(const FrameArgs* __restrict__ frames, const int n_frames, const SceneArgs S,
+__global__ void __launch_bounds__(BLOCK, DEPTH <= 16 ? kBatchWaves : 5) render_batch(const FrameArgs* __restrict__ frames, const int n_frames, const SceneArgs S,
                                                       uint8_t* __restrict__ rgb_base, const unsigned long long frame_stride,
                                                       const int first_row, const int chunk, const int xcd_swizzle) {
     __shared__ uint32_t lds_stack[DEPTH * BLOCK];
