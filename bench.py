@@ -383,6 +383,7 @@ def main():
                                           "--pmc pass, not the timed launches" % (os.path.basename(PMC_PROFILE), pmc.get("kernel")))
                 roof["valu_issue_utilisation_pmc"] = pmc.get("valu_issue_utilisation")
                 roof["valu_lane_utilisation_pmc"] = pmc.get("valu_lane_utilisation")
+                roof["vector_memory_path_busy_pmc"] = pmc.get("ta_busy")          # TA_TA_BUSY over the 256 CUs: the next limit after issue
             except Exception:
                 pass
 

@@ -58,6 +58,10 @@ def main():
         "l1_to_l2_read_requests": int(per["TCP_TCC_READ_REQ_sum"]),
         "waves": int(per["SQ_WAVES"]),
     }
+    # the vector memory path: share of cycles the 256 texture-address units were busy, and L1 accesses per CU and cycle
+    if "TA_TA_BUSY_sum" in per:
+        res["ta_busy"] = round(per["TA_TA_BUSY_sum"] / (256 * cycles), 4)
+    res["l1_accesses_per_cu_cycle"] = round(per["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256 * cycles), 4)
     os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
