@@ -122,6 +122,13 @@ def test_the_animation_job_over_two_ranks_gathers_the_same_frames():
     assert got["n_gpus"] == 2 and got["frames"] == 96 and got["equals_compiled_reference"] is True
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 @pytest.mark.gpu
 def test_the_animation_job_through_rccl_with_a_single_rank():
     """One rank under torch.distributed.run with the nccl backend: the process group is RCCL's and every batch goes through its
@@ -131,7 +138,7 @@ def test_the_animation_job_through_rccl_with_a_single_rank():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-                           "--master-port", "29731", os.path.join(repo, "scripts", "animation_job.py"), "--backend", "nccl",
+                           "--master-port", _free_port(), os.path.join(repo, "scripts", "animation_job.py"), "--backend", "nccl",
                            "--collective-at-one-rank"], capture_output=True, text=True, timeout=300, env=env)
     assert proc.returncode == 0, proc.stderr[-3000:]
     got = [json.loads(ln) for ln in proc.stdout.splitlines() if ln.startswith("{") and '"job"' in ln]
@@ -147,7 +154,7 @@ def test_bench_through_rccl_with_a_single_rank():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-                           "--master-port", "29733", os.path.join(repo, "bench.py"), "--collective-at-one-rank", "--steps", "16", "--warmup", "8",
+                           "--master-port", _free_port(), os.path.join(repo, "bench.py"), "--collective-at-one-rank", "--steps", "16", "--warmup", "8",
                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
     assert proc.returncode == 0, proc.stderr[-3000:]
     out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0])

@@ -265,7 +265,7 @@ def test_bench_single_rank_can_go_through_the_process_group():
     import subprocess
     env = dict(os.environ)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-                        "--master-port", "29741", os.path.join(REPO, "bench.py"), "--rehearse-cpu", "--collective-at-one-rank", "--steps", "8",
+                        "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--rehearse-cpu", "--collective-at-one-rank", "--steps", "8",
                         "--warmup", "2", "--width", "64", "--height", "36", "--batch", "4"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
