@@ -54,7 +54,7 @@ hipError_t launch_batch_noalloc(int device, const FrameArgs* h_frames, int n_fra
 hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneArgs& S, const OutputPlanes& O, int block, int split, hipStream_t stream);
 
 // Enqueues one frame of an instanced scene.  I.inst holds one MeshArgs per instance (pair ranges inside
-// S.pairs, live tris/attrs/texels), I.tlas / I.order the hierarchy over the non-empty ones, its depth at
+// S.pairs, live tris/attrs/texels), I.tlas the hierarchy over the non-empty ones (leaves name their instance: write_direct in rt_pack.h), its depth at
 // most kTlasStackDepth - 2.  O.hit_id receives the instance index, hit_tri (optional) the triangle.
 // wave_tiles > 0 (and no work counting): the per-wavefront scheduler of rt_instanced_wave.h, a wave per strip of that many tiles.
 hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const SceneArgs& S, const OutputPlanes& O, int32_t* hit_tri,
