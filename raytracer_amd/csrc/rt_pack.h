@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <string>
+#include <future>
 #include <vector>
 
 #include "../../include/rt_mi355.h"
@@ -172,7 +173,7 @@ public:
         out_.tree_pairs = (uint32_t)out_.pairs.size();
         out_.empty = false;
         if (out_.depth + 2 > kStackDepth || out_.depth > RT_MAX_TREE_DEPTH) { err = "BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
-        if (regroup_ && leaves_ok_ && leaves_.size() >= 4 && leaves_.size() <= ((size_t)1 << 20)) regroup();
+        if (regroup_ && leaves_ok_ && leaves_.size() >= 4 && leaves_.size() <= ((size_t)1 << 23)) regroup();
         if (regroup_) build_grid();
         return RT_OK;
     }
@@ -266,7 +267,9 @@ private:
     }
 
     // Builds the subtree over items [first, first + count) into `fast`; returns its reference and box.
-    uint32_t regroup_range(std::vector<PairNode>& fast, size_t first, size_t count, int depth, int& deepest, float* lo, float* hi) {
+    // Node numbering is pre-order (a node, its left subtree, its right subtree): the subtree over `count` leaves owns the
+    // count - 1 records from `base` on, so the two halves of a large range can be built by two threads at once.
+    uint32_t regroup_range(std::vector<PairNode>& fast, uint32_t base, size_t first, size_t count, int depth, int& deepest, float* lo, float* hi) {
         LeafItem* it = leaves_.data() + first;
         for (int a = 0; a < 3; a++) { lo[a] = it[0].lo[a]; hi[a] = it[0].hi[a]; }
         if (count == 1) return it[0].ref;
@@ -327,23 +330,32 @@ private:
             }
             n_left = l;
         }
-        const uint32_t me = (uint32_t)fast.size();
-        fast.emplace_back();
+        const uint32_t me = base;
         if (depth + 1 > deepest) deepest = depth + 1;
         PairNode p;
-        const uint32_t l = regroup_range(fast, first, n_left, depth + 1, deepest, p.lmin, p.lmax);
-        const uint32_t r = regroup_range(fast, first + n_left, count - n_left, depth + 1, deepest, p.rmin, p.rmax);
+        uint32_t l, r;
+        const uint32_t rbase = base + (uint32_t)n_left;                  // the left subtree takes base + 1 .. base + n_left - 1
+        if (count >= kRegroupParallelMin && depth < 5) {
+            int deep_left = 0;
+            auto left = std::async(std::launch::async, [&]() { return regroup_range(fast, base + 1, first, n_left, depth + 1, deep_left, p.lmin, p.lmax); });
+            r = regroup_range(fast, rbase, first + n_left, count - n_left, depth + 1, deepest, p.rmin, p.rmax);
+            l = left.get();
+            if (deep_left > deepest) deepest = deep_left;
+        } else {
+            l = regroup_range(fast, base + 1, first, n_left, depth + 1, deepest, p.lmin, p.lmax);
+            r = regroup_range(fast, rbase, first + n_left, count - n_left, depth + 1, deepest, p.rmin, p.rmax);
+        }
         p.lref = l; p.rref = r; p.pad[0] = p.pad[1] = 0;
         fast[me] = p;
         return me;
     }
+    static constexpr size_t kRegroupParallelMin = (size_t)1 << 16;
 
     void regroup() {
-        std::vector<PairNode> fast;
-        fast.reserve(leaves_.size());
+        std::vector<PairNode> fast(leaves_.size() - 1);
         int deepest = 0;
         float lo[3], hi[3];
-        const uint32_t root = regroup_range(fast, 0, leaves_.size(), 0, deepest, lo, hi);
+        const uint32_t root = regroup_range(fast, 0, 0, leaves_.size(), 0, deepest, lo, hi);
         if (deepest + 2 > kStackDepth || deepest > RT_MAX_TREE_DEPTH) return;        // keep the reference's tree only
         const uint32_t shift = (uint32_t)fast.size();
         for (PairNode p : out_.pairs) {                           // the reference's tree moves behind the new one

@@ -50,6 +50,7 @@ def main():
     p.add_argument("--frames", default="0,45")
     p.add_argument("--reps", type=int, default=5)
     p.add_argument("--host-build", action="store_true")
+    p.add_argument("--no-regroup", action="store_true", help="host build: keep only the reference's tree (option regroup = 0)")
     p.add_argument("--profile", action="store_true", help="no work-counting launches: the program a profiler is pointed at")
     a = p.parse_args()
     from raytracer_amd import capi, demo, host_api
@@ -65,6 +66,8 @@ def main():
     ctx.upload_host_mesh(scene.meshes[0])
     if a.host_build:
         ctx.set_option("device_build_min", 1 << 30)
+    if a.no_regroup:
+        ctx.set_option("regroup", 0)
     t0 = time.perf_counter()
     ctx.upload_soup(soup, rgba[1])                              # BVH build + packing + upload in one call
     t_build = time.perf_counter() - t0
