@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""A long random run of the parity check the GPU tests make on six scenes: the reference driver's three meshes under random
+placements (anywhere within a few units, any rotation, the ground tilted), cameras anywhere around and inside them (looking at a
+random point, field of view 15..120 degrees), random light directions, frame sizes that are not multiples of the tile; every
+plane of the HIP path (rgb, hit id, bits of the closest t, shadow flag) against the CPU oracle, which is test infrastructure.
+Prints one JSON line; exits non-zero on the first scene that differs and says which.
+
+    python scripts/soak_parity.py --scenes 1000 --seed 1
+"""
+import argparse
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--scenes", type=int, default=500)
+    p.add_argument("--seed", type=int, default=1)
+    a = p.parse_args()
+    import torch  # noqa: F401  (its HIP runtime first)
+    from oracle import pyoracle as po
+    from raytracer_amd import capi
+    po.lib()
+    meshes = po.default_meshes()
+    ctx = capi.Context(0)
+    for m in meshes:
+        ctx.upload_mesh(m.tris, m.nodes, m.rgba)
+    rng = np.random.default_rng(a.seed)
+    sizes = [(160, 90), (200, 120), (97, 61), (33, 130), (256, 8)]
+    pixels = hits = 0
+    for k in range(a.scenes):
+        spread = float(rng.choice([0.5, 1.5, 5.0, 50.0]))
+        tfs = []
+        for m in range(3):
+            pos = rng.uniform(-spread, spread, 3)
+            rot = rng.uniform(-3.2, 3.2, 3) if (m < 2 or rng.uniform() < 0.3) else rng.uniform(-0.05, 0.05, 3)
+            tfs.append(po.Transform(po.vec3(*pos), po.vec3(*rot)))
+        eye = rng.uniform(-1.2 * spread - 2, 1.2 * spread + 2, 3)
+        at = rng.uniform(-spread, spread, 3)
+        if np.linalg.norm(eye - at) < 1e-3:
+            at = eye + np.array([0.3, -0.2, 0.9])
+        fov = float(rng.uniform(15, 120))
+        up = (0, 1, 0) if rng.uniform() < 0.8 else tuple(rng.normal(size=3))
+        ocam = po.Camera(po.vec3(*eye), po.vec3(*at), po.vec3(*up), fov)
+        olight = po.lib().orc_make_light(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(0.3, 1.6, 3)))
+        cam = capi.Camera(capi.Vec3(*ocam.position.tup()), capi.Vec3(*ocam.look_at.tup()), capi.Vec3(*ocam.up.tup()), fov)
+        light = capi.Light(capi.Vec3(*olight.direction.tup()), capi.Vec3(*olight.color.tup()))
+        w, h = sizes[k % len(sizes)]
+        want = po.render_frame(meshes, tfs, ocam, olight, w, h)
+        ctfs = [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in tfs]
+        rgb, hid, ht, sh = ctx.render_host(cam, light, ctfs, w, h)
+        same = (np.array_equal(hid, want.hit_id) and np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32))
+                and np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb))
+        if not same:
+            print(json.dumps({"scene": k, "seed": a.seed, "size": [w, h], "ids_differ": int((hid != want.hit_id).sum()),
+                              "t_differ": int((ht.view(np.uint32) != want.hit_t.view(np.uint32)).sum()),
+                              "shadow_differ": int((sh != want.shadow).sum()), "rgb_differ": int((rgb != want.rgb).any(-1).sum())}))
+            sys.exit(1)
+        pixels += w * h
+        hits += int((want.hit_id >= 0).sum())
+        if (k + 1) % 100 == 0:
+            print(f"[soak] {k + 1} scenes identical", file=sys.stderr, flush=True)
+    print(json.dumps({"scenes": a.scenes, "seed": a.seed, "pixels": pixels, "pixels_with_a_hit": hits,
+                      "planes": "rgb, hit id, closest t (bits), shadow", "identical": True}))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
