@@ -17,11 +17,69 @@ sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 
 
+def instanced(a):
+    import torch
+    from oracle import pyoracle as po
+    from raytracer_amd import capi
+    po.lib()
+    meshes = po.default_meshes()
+    ctx = capi.Context(0)
+    for m in meshes:
+        ctx.upload_mesh(m.tris, m.nodes, m.rgba)
+    rng = np.random.default_rng(a.seed)
+    sizes = [(160, 90), (97, 61), (200, 40)]
+    pixels = hits = 0
+    dev = "cuda:0"
+    for k in range(a.scenes):
+        n = int(rng.integers(1, 41))
+        spread = float(rng.choice([1.0, 3.0, 8.0]))
+        ids = [int(rng.choice([0, 1, 1, 1, 2])) for _ in range(n)]
+        tfs = [po.Transform(po.vec3(*rng.uniform(-spread, spread, 3)), po.vec3(*rng.uniform(-3.2, 3.2, 3))) for _ in range(n)]
+        if n > 3 and rng.uniform() < 0.3:                       # coincident entries: the earlier one wins
+            tfs[n - 1] = tfs[0]; ids[n - 1] = ids[0]
+        eye = rng.uniform(-1.2 * spread - 2, 1.2 * spread + 2, 3)
+        at = rng.uniform(-spread, spread, 3)
+        if np.linalg.norm(eye - at) < 1e-3:
+            at = eye + np.array([0.3, -0.2, 0.9])
+        fov = float(rng.uniform(20, 110))
+        ocam = po.Camera(po.vec3(*eye), po.vec3(*at), po.vec3(0, 1, 0), fov)
+        olight = po.lib().orc_make_light(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(0.3, 1.6, 3)))
+        cam = capi.Camera(capi.Vec3(*ocam.position.tup()), capi.Vec3(*ocam.look_at.tup()), capi.Vec3(0, 1, 0), fov)
+        light = capi.Light(capi.Vec3(*olight.direction.tup()), capi.Vec3(*olight.color.tup()))
+        w, h = sizes[k % len(sizes)]
+        fr, inst, tri = po.render_frame_ids([meshes[i] for i in ids], tfs, ocam, olight, w, h)
+        lst = capi.Context.make_instances(ids, [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in tfs])
+        rgb = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+        hi = torch.empty((h, w), dtype=torch.int32, device=dev)
+        htri = torch.empty((h, w), dtype=torch.int32, device=dev)
+        t = torch.empty((h, w), dtype=torch.float32, device=dev)
+        sh = torch.empty((h, w), dtype=torch.uint8, device=dev)
+        ctx.render_instanced(cam, light, lst, w, h, rgb, hit_instance=hi, hit_tri=htri, hit_t=t, shadow=sh)
+        ctx.sync()
+        same = (np.array_equal(hi.cpu().numpy(), inst) and np.array_equal(htri.cpu().numpy(), tri)
+                and np.array_equal(t.cpu().numpy().view(np.uint32), fr.hit_t.view(np.uint32))
+                and np.array_equal(sh.cpu().numpy(), fr.shadow) and np.array_equal(rgb.cpu().numpy(), fr.rgb))
+        if not same:
+            print(json.dumps({"scene": k, "seed": a.seed, "instances": n, "size": [w, h], "differs": True}))
+            sys.exit(1)
+        pixels += w * h
+        hits += int((inst >= 0).sum())
+        if (k + 1) % 100 == 0:
+            print(f"[soak] {k + 1} instanced scenes identical", file=sys.stderr, flush=True)
+    print(json.dumps({"scenes": a.scenes, "seed": a.seed, "path": "rt_render_frame_instanced, lists of 1..40 placed meshes", "pixels": pixels,
+                      "pixels_with_a_hit": hits, "planes": "rgb, instance, triangle, closest t (bits), shadow", "identical": True}))
+    ctx.close()
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--scenes", type=int, default=500)
     p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--instanced", action="store_true",
+                   help="lists of 1..40 placed meshes through rt_render_frame_instanced against the reference's loop over the list")
     a = p.parse_args()
+    if a.instanced:
+        return instanced(a)
     import torch  # noqa: F401  (its HIP runtime first)
     from oracle import pyoracle as po
     from raytracer_amd import capi
