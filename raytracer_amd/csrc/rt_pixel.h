@@ -78,6 +78,23 @@ RT_HD AttrRec read_attrs(const AttrRec* attrs, uint32_t index) { return attrs[in
 RT_HD uint32_t read_word(const uint32_t* words, size_t index) { return words[index]; }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// A node that every active lane of the wave is at: one read through the scalar cache into scalar registers instead of
+// sixty-four through the vector memory path.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ PairNode read_pair_uniform(const PairNode* pairs, uint32_t index) {
+    const u32x16 w = *(const __attribute__((address_space(4))) u32x16*)((const __attribute__((address_space(4))) char*)pairs + (size_t)index * sizeof(PairNode));
+    PairNode n;
+    n.lmin[0] = __uint_as_float(w[0]); n.lmin[1] = __uint_as_float(w[1]); n.lmin[2] = __uint_as_float(w[2]);
+    n.lmax[0] = __uint_as_float(w[3]); n.lmax[1] = __uint_as_float(w[4]); n.lmax[2] = __uint_as_float(w[5]);
+    n.rmin[0] = __uint_as_float(w[6]); n.rmin[1] = __uint_as_float(w[7]); n.rmin[2] = __uint_as_float(w[8]);
+    n.rmax[0] = __uint_as_float(w[9]); n.rmax[1] = __uint_as_float(w[10]); n.rmax[2] = __uint_as_float(w[11]);
+    n.lref = w[12]; n.rref = w[13]; n.pad[0] = n.pad[1] = 0;
+    return n;
+}
+template <class Nodes> struct ScalarNodes { static constexpr bool on = false; __device__ static const PairNode* base(const Nodes&) { return nullptr; } };
+#endif
+
 // Node source: where PairNodes are read from.  GlobalNodes reads the scene's combined node array
 // through the vector cache; the kernels also have a source that reads a copy staged in LDS.
 struct GlobalNodes {
@@ -85,6 +102,10 @@ struct GlobalNodes {
     RT_HD const PairNode& operator()(const MeshArgs& M, uint32_t ref) const { return all[M.pair_base + ref]; }
     RT_HD TriRec tri(const MeshArgs& M, uint32_t index) const { return read_tri(M.tris, index); }
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+template <> struct ScalarNodes<GlobalNodes> { static constexpr bool on = true; __device__ static const PairNode* base(const GlobalNodes& n) { return n.all; } };
+#endif
 
 // Distance culling (used unless the caller asks for the reference's visiting order).
 // A subtree is skipped when its box is entered farther away than the closest accepted hit.  Both
@@ -178,11 +199,8 @@ template <bool ANY, bool COUNT, bool FULL, uint32_t LB, class Nodes>
 RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, F3 d, Query& q, Work& work) {
     constexpr bool CULL = !FULL && !ANY;
     const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
-    for (uint32_t i0 = 0; i0 < count; i0 += LB) {
-        TriRec T[LB];                                          // registers: every index below is a constant
-        const uint32_t n = count - i0 < LB ? count - i0 : LB;
-        RT_UNROLL
-        for (uint32_t k = 0; k < LB; k++) T[k] = nodes.tri(M, first + i0 + (k < n ? k : 0));
+    // the tests of one batch of fetched triangles; returns true when an any-hit query may stop
+    auto batch = [&](const TriRec (&T)[LB], uint32_t i0, uint32_t n) {
         RT_UNROLL
         for (uint32_t k = 0; k < LB; k++) {
             if (k >= n) continue;
@@ -200,6 +218,14 @@ RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, 
                 if (CULL && t < q.bound) q.limit = cull_limit(t);
             }
         }
+        return false;
+    };
+    for (uint32_t i0 = 0; i0 < count; i0 += LB) {
+        TriRec T[LB];                                          // registers: every index below is a constant
+        const uint32_t n = count - i0 < LB ? count - i0 : LB;
+        RT_UNROLL
+        for (uint32_t k = 0; k < LB; k++) T[k] = nodes.tri(M, first + i0 + (k < n ? k : 0));
+        if (batch(T, i0, n)) return true;
     }
     return false;
 }
@@ -277,9 +303,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
         if (M.grid_axis < 3u && ref == M.root_ref && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ref = grid_entry(M, o, d, inv, ref);
         bool live = true;
         while (live) {
-            while (live && !(ref & kLeafBit)) {
-                if (BUDGET && --steps < 0) return false;
-                const PairNode N = nodes(M, ref);
+            auto step = [&](const PairNode& N) {
                 if (COUNT) work.slabs += 2;
                 float tl, tr;
                 bool hl, hr;
@@ -296,6 +320,24 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
                 } else {
                     ref = stack.pop();
                 }
+            };
+            while (live && !(ref & kLeafBit)) {
+                if (BUDGET && --steps < 0) return false;
+#if defined(__HIP_DEVICE_COMPILE__)
+                // Neighbouring rays mostly walk the same nodes at the same time (two thirds of all node visits happen with every
+                // active lane of the wave at one node): such a node is read once through the scalar cache, and the vector memory
+                // path -- whose address unit is busy 16 cycles per 16-byte-per-lane load and was this loop's limit -- is spared
+                // four loads.  Same arithmetic on the same bits either way.
+                if (ScalarNodes<Nodes>::on) {
+                    const uint32_t idx = M.pair_base + ref;
+                    const uint32_t uidx = __builtin_amdgcn_readfirstlane(idx);
+                    if (__builtin_amdgcn_ballot_w64(idx != uidx) == 0) {
+                        step(read_pair_uniform(ScalarNodes<Nodes>::base(nodes), uidx));
+                        continue;
+                    }
+                }
+#endif
+                step(nodes(M, ref));
             }
             if (live) {
                 if (BUDGET && --steps < 0) return false;
