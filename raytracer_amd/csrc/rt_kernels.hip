@@ -125,8 +125,10 @@ static hipError_t launch_direct(const FrameArgs& A, const SceneArgs& S, const Ou
 // Sampled frames (rt_sampled.h): several camera rays per pixel, several lights.  One thread per
 // pixel loops over its samples, so the lanes of a wave stay on neighbouring rays throughout.
 // ------------------------------------------------------------------------------------------
+// Six waves per SIMD (80 registers, 8 bytes of scratch): 8.0 ms instead of 8.3 for the 4K / 16-sample / 2-light frame (mean of
+// frames 0 and 45); seven waves the same, eight slower.
 template <int BLOCK, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) render_sampled(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
+__global__ void __launch_bounds__(BLOCK, 6) render_sampled(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
     extern __shared__ uint32_t lds_stack[];                      // S.stack_entries x BLOCK words
     LdsStack<BLOCK> stack;
     stack.init(&lds_stack[threadIdx.x]);
@@ -263,8 +265,9 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
 // the instances' world boxes.  Two per-lane stacks in LDS: one for the walk over the hierarchy,
 // one for the walk inside an instance's BVH.
 // ------------------------------------------------------------------------------------------
+// Five waves per SIMD (96 registers, 28 bytes of scratch): 1.29 against 1.31 ms at four; six waves spill 96 bytes and lose.
 template <int BLOCK, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) render_instanced(const FrameArgs A, const InstancedArgs I, const SceneArgs S, const OutputPlanes O,
+__global__ void __launch_bounds__(BLOCK, 5) render_instanced(const FrameArgs A, const InstancedArgs I, const SceneArgs S, const OutputPlanes O,
                                                           int32_t* __restrict__ hit_tri, const int tlas_entries) {
     // both stacks sized for the trees at hand (entries x BLOCK words each): LDS per wave decides how many
     // waves a CU holds here
@@ -484,14 +487,15 @@ static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const Outp
 // per-frame constants share the scalar cache).  The per-frame constants come from an array
 // in device memory; the frame index is uniform per wave, so they are read with scalar loads.
 // ------------------------------------------------------------------------------------------
-// Six waves per SIMD (80 registers, no spills) where the short stack leaves room in LDS: with meshes skipped per tile the
-// kernel waits for memory more than it did, and a sixth wave hides it (1.217 -> 1.158 ms per launch of 8 frames; seven
-// waves spill 40 bytes per lane and give the gain back, eight lose 20 %).
-// The fast build keeps six values more in registers (fused operands): at six waves it would spill, it runs five.
+// Eight waves per SIMD where the short stack leaves room in LDS.  The kernel's issue slots are ~95 % busy, its lanes wait on
+// dependent loads, and every further wave hides more of that: six waves 1.023 ms per launch of 8 frames, seven 0.979, eight
+// 0.970 -- the last at 64 registers with 28 bytes of scratch per lane, which costs less than the eighth wave brings.  (Built
+// with the SLP vectorizer the kernel needed 80 registers and lost at seven waves and above.)
+// The fast build fits seven waves without scratch (72 registers) and is fastest there (0.909 against 0.914 ms at eight).
 #if defined(RT_FAST)
-constexpr int kBatchWaves = 5;
+constexpr int kBatchWaves = 7;
 #else
-constexpr int kBatchWaves = 6;
+constexpr int kBatchWaves = 8;
 #endif
 template <int BLOCK, int DEPTH, uint32_t LB>
 __global__ void __launch_bounds__(BLOCK, DEPTH <= 16 ? kBatchWaves : 5) render_batch(const FrameArgs* __restrict__ frames, const int n_frames, const SceneArgs S,
