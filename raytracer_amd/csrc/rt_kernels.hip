@@ -487,16 +487,12 @@ static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const Outp
 // per-frame constants share the scalar cache).  The per-frame constants come from an array
 // in device memory; the frame index is uniform per wave, so they are read with scalar loads.
 // ------------------------------------------------------------------------------------------
-// Eight waves per SIMD where the short stack leaves room in LDS.  The kernel's issue slots are ~95 % busy, its lanes wait on
-// dependent loads, and every further wave hides more of that: six waves 1.023 ms per launch of 8 frames, seven 0.979, eight
-// 0.970 -- the last at 64 registers with 28 bytes of scratch per lane, which costs less than the eighth wave brings.  (Built
-// with the SLP vectorizer the kernel needed 80 registers and lost at seven waves and above.)
-// The fast build fits seven waves without scratch (72 registers) and is fastest there (0.909 against 0.914 ms at eight).
-#if defined(RT_FAST)
+// Seven waves per SIMD where the short stack leaves room in LDS.  The kernel's issue slots are ~95 % busy, its lanes wait on
+// dependent loads, and every further wave hides more of that: six waves 1.023 ms per launch of 8 frames, seven 0.979 (71
+// registers, nothing spilled; the fast build 72 and 0.909).  Eight waves run 0.970, but at 64 registers with 28 bytes of scratch
+// per lane, which come back as 230 MB of writes to memory per launch: not worth one per cent.  (Built with the SLP vectorizer
+// the kernel needed 80 registers and lost at seven waves and above.)
 constexpr int kBatchWaves = 7;
-#else
-constexpr int kBatchWaves = 8;
-#endif
 template <int BLOCK, int DEPTH, uint32_t LB>
 __global__ void __launch_bounds__(BLOCK, DEPTH <= 16 ? kBatchWaves : 5) render_batch(const FrameArgs* __restrict__ frames, const int n_frames, const SceneArgs S,
                                                       uint8_t* __restrict__ rgb_base, const unsigned long long frame_stride,
