@@ -47,7 +47,10 @@ def main():
         "hbm_bytes_per_launch": int(fetch_raw * 2 + write),
         "gpu_cycles_per_launch": int(cycles),
         "valu_wave_instructions": int(per["SQ_INSTS_VALU"]),
-        "valu_issue_utilisation": round(per["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * N_SIMD), 4),
+        # four cycles per wave64 instruction is the full-width cost; the ratio can pass 1 (instructions whose upper lanes are all
+        # off cost less), which then simply means the vector pipes never idle
+        "valu_issue_utilisation": round(min(1.0, per["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * N_SIMD)), 4),
+        "valu_issue_ratio_at_4_cycles_per_instruction": round(per["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * N_SIMD), 4),
         "valu_lane_utilisation": round(per["SQ_THREAD_CYCLES_VALU"] / (per["SQ_ACTIVE_INST_VALU"] * 4 * 16), 4),
         "salu_wave_instructions": int(per["SQ_INSTS_SALU"]),
         "vmem_read_wave_instructions": int(per["SQ_INSTS_VMEM_RD"]),
