@@ -178,7 +178,45 @@ public:
         return RT_OK;
     }
 
+    // The second tree for a mesh whose reference tree was packed elsewhere (on the device): pk.pairs / pk.root_ref hold that
+    // tree, every leaf one reference.  Its leaves are collected in the reference's visiting order (everything below the left
+    // child, then everything below the right one) with the boxes their parents hold for them, and pk gets what run() would
+    // have given it.  Returns false when nothing was done (a single leaf, fewer than four leaves, more than the limit, a
+    // malformed or too deep tree).
+    static bool regroup_packed(PackedMesh& pk) {
+        if ((pk.root_ref & kLeafBit) || pk.pairs.empty()) return false;
+        Packer P(nullptr, 0, nullptr, 0, pk, true);
+        struct Visit { uint32_t node; int stage; };
+        std::vector<Visit> path(1, Visit{pk.root_ref, 0});
+        size_t visited = 0;
+        while (!path.empty()) {
+            const size_t top = path.size() - 1;
+            const uint32_t node = path[top].node;
+            const int stage = path[top].stage++;
+            if (node >= pk.pairs.size() || path.size() > (size_t)RT_MAX_TREE_DEPTH + 8) return false;
+            const PairNode& n = pk.pairs[node];
+            if (stage == 0) {
+                if (++visited > pk.pairs.size()) return false;                 // not a tree
+                if (n.lref & kLeafBit) P.note_leaf(n.lmin, n.lmax, n.lref); else path.push_back(Visit{n.lref, 0});
+            } else if (stage == 1) {
+                if (n.rref & kLeafBit) P.note_leaf(n.rmin, n.rmax, n.rref); else path.push_back(Visit{n.rref, 0});
+            } else {
+                path.pop_back();
+            }
+        }
+        if (P.leaves_.size() < 4 || P.leaves_.size() > ((size_t)1 << 23)) return false;
+        const uint32_t before = pk.root_ref;
+        P.regroup();
+        return pk.root_ref != before || pk.ref_root != before;
+    }
+
 private:
+    void note_leaf(const float* lo, const float* hi, uint32_t ref) {
+        LeafItem it;
+        memcpy(it.lo, lo, 12); memcpy(it.hi, hi, 12);
+        it.ref = ref;
+        leaves_.push_back(it);
+    }
     int emit(int32_t ni, int depth, uint32_t& ref, std::string& err) {
         if (ni < 0 || ni >= n_nodes_) { err = "node index out of range"; return RT_ERR_INVALID; }
         if (visited_[(size_t)ni]) { err = "node reachable twice (not a tree)"; return RT_ERR_INVALID; }
