@@ -125,10 +125,10 @@ static hipError_t launch_direct(const FrameArgs& A, const SceneArgs& S, const Ou
 // Sampled frames (rt_sampled.h): several camera rays per pixel, several lights.  One thread per
 // pixel loops over its samples, so the lanes of a wave stay on neighbouring rays throughout.
 // ------------------------------------------------------------------------------------------
-// Six waves per SIMD (80 registers, 8 bytes of scratch): 8.0 ms instead of 8.3 for the 4K / 16-sample / 2-light frame (mean of
-// frames 0 and 45); seven waves the same, eight slower.
+// Seven waves per SIMD (71 registers, nothing spilled): 7.9 ms instead of 8.3 at five waves for the 4K / 16-sample / 2-light frame
+// (mean of frames 0 and 45).
 template <int BLOCK, bool COUNT>
-__global__ void __launch_bounds__(BLOCK, 6) render_sampled(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
+__global__ void __launch_bounds__(BLOCK, 7) render_sampled(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
     extern __shared__ uint32_t lds_stack[];                      // S.stack_entries x BLOCK words
     LdsStack<BLOCK> stack;
     stack.init(&lds_stack[threadIdx.x]);
@@ -265,7 +265,7 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
 // the instances' world boxes.  Two per-lane stacks in LDS: one for the walk over the hierarchy,
 // one for the walk inside an instance's BVH.
 // ------------------------------------------------------------------------------------------
-// Five waves per SIMD (96 registers, 28 bytes of scratch): 1.29 against 1.31 ms at four; six waves spill 96 bytes and lose.
+// Five waves per SIMD (90 registers, nothing spilled): 1.25 against 1.31 ms at four; six and seven waves spill and lose.
 template <int BLOCK, bool COUNT>
 __global__ void __launch_bounds__(BLOCK, 5) render_instanced(const FrameArgs A, const InstancedArgs I, const SceneArgs S, const OutputPlanes O,
                                                           int32_t* __restrict__ hit_tri, const int tlas_entries) {
@@ -487,12 +487,11 @@ static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const Outp
 // per-frame constants share the scalar cache).  The per-frame constants come from an array
 // in device memory; the frame index is uniform per wave, so they are read with scalar loads.
 // ------------------------------------------------------------------------------------------
-// Seven waves per SIMD where the short stack leaves room in LDS.  The kernel's issue slots are ~95 % busy, its lanes wait on
-// dependent loads, and every further wave hides more of that: six waves 1.023 ms per launch of 8 frames, seven 0.979 (71
-// registers, nothing spilled; the fast build 72 and 0.909).  Eight waves run 0.970, but at 64 registers with 28 bytes of scratch
-// per lane, which come back as 230 MB of writes to memory per launch: not worth one per cent.  (Built with the SLP vectorizer
-// the kernel needed 80 registers and lost at seven waves and above.)
-constexpr int kBatchWaves = 7;
+// Eight waves per SIMD (the most a SIMD holds) where the short stack leaves room in LDS.  The kernel's vector pipes are
+// saturated and its lanes wait on dependent loads; every further wave hides more of that: per launch of 8 frames, with two
+// triangles fetched per leaf batch (71 registers) six waves 1.023 ms, seven 0.979, eight 0.970 with 28 bytes of scratch; with one
+// triangle per batch (59 registers, nothing spilled) eight waves 0.935 ms, the fast build 0.870.
+constexpr int kBatchWaves = 8;
 template <int BLOCK, int DEPTH, uint32_t LB>
 __global__ void __launch_bounds__(BLOCK, DEPTH <= 16 ? kBatchWaves : 5) render_batch(const FrameArgs* __restrict__ frames, const int n_frames, const SceneArgs S,
                                                       uint8_t* __restrict__ rgb_base, const unsigned long long frame_stride,
