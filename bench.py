@@ -60,7 +60,7 @@ def parse(argv=None):
     p.add_argument("--warmup", type=int, default=16)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--batch", type=int, default=8, help="frames per launch (and per gather message for N > 1)")
+    p.add_argument("--batch", type=int, default=FRAMES_PER_LAUNCH, help="frames per launch (and per gather message for N > 1)")
     p.add_argument("--block", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--verbose", action="store_true", help="phase markers on stderr")
@@ -76,6 +76,9 @@ def parse(argv=None):
     p.add_argument("--cpu-frames", type=int, default=8)
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port when this program starts its own ranks (0 = a free one)")
     return p.parse_args(argv)
+
+
+FRAMES_PER_LAUNCH = 16        # RT_MAX_BATCH: the tail of a launch is shared by more frames (8 per launch: 5 % slower)
 
 
 def frame_sequence(share, n):
@@ -379,11 +382,13 @@ def main():
             try:        # counters of a separate rocprofv3 --pmc pass over this same command (scripts/gpu_pmc.sh), per launch
                 pmc = json.load(open(PMC_PROFILE))
                 hbm = pmc.get("hbm_bytes_per_launch")
+                if hbm:
+                    hbm = int(hbm * a.batch / float(pmc.get("frames_per_launch", 8)))      # the counter pass's launches may hold fewer frames
                 roof["traffic"] = hbm
                 if hbm:
                     roof["hbm_frac"] = round(hbm / secs / 1e9 / HBM_PEAK_GBS, 5)
-                roof["traffic_source"] = ("profiles/%s: FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per %s launch of 8 frames, separate "
-                                          "--pmc pass, not the timed launches" % (os.path.basename(PMC_PROFILE), pmc.get("kernel")))
+                roof["traffic_source"] = ("profiles/%s: FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per %s launch of %d frames, separate "
+                                          "--pmc pass, not the timed launches" % (os.path.basename(PMC_PROFILE), pmc.get("kernel"), a.batch))
                 roof["valu_issue_utilisation_pmc"] = pmc.get("valu_issue_utilisation")
                 roof["valu_lane_utilisation_pmc"] = pmc.get("valu_lane_utilisation")
                 roof["vector_memory_path_busy_pmc"] = pmc.get("ta_busy")          # TA_TA_BUSY over the 256 CUs: the next limit after issue

@@ -23,5 +23,5 @@ rc=$?; echo "rocprof exit $rc"; [ $rc -ne 0 ] && exit $rc
 f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -n 8 "$f"
 bash scripts/gpu_pmc.sh bench --mode bench --repeat 1 > gpurun_out/pmc_bench.log 2>&1
 rc=$?; tail -n 30 gpurun_out/pmc_bench.log; [ $rc -ne 0 ] && exit $rc
-python3 scripts/pmc_to_profile.py gpurun_out/pmc_bench render_batch gpurun_out/r2_traffic.json > /dev/null
+python3 scripts/pmc_to_profile.py gpurun_out/pmc_bench render_batch gpurun_out/r2_traffic.json 16 > /dev/null
 cat gpurun_out/r2_traffic.json

@@ -2,7 +2,7 @@
 """Condenses the counter passes of scripts/gpu_pmc.sh into one JSON file that bench.py reads for
 the `traffic` and VALU figures of its roofline object.
 
-    python scripts/pmc_to_profile.py gpurun_out/pmc_bench render_batch profiles/r2_traffic.json
+    python scripts/pmc_to_profile.py gpurun_out/pmc_bench render_batch profiles/r2_traffic.json 16     # frames per profiled launch
 
 HBM bytes per launch: FETCH_SIZE and WRITE_SIZE are reported in KiB and were collected in separate
 passes.  On gfx950 FETCH_SIZE counts 64 B for every memory-side read request although wide requests
@@ -23,6 +23,7 @@ N_XCD, N_SIMD = 8, 1024
 
 def main():
     root, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    frames_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 8
     tot = defaultdict(float)
     disp = defaultdict(set)
     for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -41,6 +42,7 @@ def main():
         "kernel": kernel,
         "source": os.path.basename(os.path.normpath(root)),
         "launches_profiled": max(len(v) for v in disp.values()),
+        "frames_per_launch": frames_per_launch,
         "hbm_fetch_bytes_reported": int(fetch_raw),
         "hbm_fetch_bytes_corrected": int(fetch_raw * 2),
         "hbm_write_bytes": int(write),

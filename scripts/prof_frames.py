@@ -59,7 +59,7 @@ def main():
     p.add_argument("--repeat", type=int, default=2)
     p.add_argument("--batch", type=int, default=0, help="> 0: rt_render_frames with this many consecutive frames per launch")
     p.add_argument("--mode", default="frames", choices=["frames", "bench", "sampled", "instanced", "upscale"],
-                   help="bench: the launches of bench.py's timed region (96 steps, 8 frames per launch); sampled: 4K/16 samples/2 lights; instanced: 56x56 treasures; upscale: 16 frames 1080p -> scale 0.9")
+                   help="bench: the launches of bench.py's timed region (96 steps, bench.FRAMES_PER_LAUNCH frames per launch); sampled: 4K/16 samples/2 lights; instanced: 56x56 treasures; upscale: 16 frames 1080p -> scale 0.9")
     p.add_argument("--wave", type=int, default=-1, help="option instanced_wave (instanced mode)")
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
@@ -77,10 +77,11 @@ def main():
     if a.mode == "bench":
         import bench
         seq = bench.frame_sequence(list(range(demo.N_FRAMES)), 96)
-        buf = torch.empty((8, a.height, a.width, 3), dtype=torch.uint8, device=dev)
+        n = bench.FRAMES_PER_LAUNCH
+        buf = torch.empty((n, a.height, a.width, 3), dtype=torch.uint8, device=dev)
         for _ in range(a.repeat):
-            for b in range(0, 96, 8):
-                scene.render_frames(seq[b:b + 8], a.width, a.height, buf)
+            for b in range(0, 96, n):
+                scene.render_frames(seq[b:b + n], a.width, a.height, buf)
         scene.ctx.sync()
         torch.cuda.synchronize()
         scene.close()
