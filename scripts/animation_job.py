@@ -28,7 +28,7 @@ def parse(argv):
     p.add_argument("--width", type=int, default=720)
     p.add_argument("--height", type=int, default=540)
     p.add_argument("--scale", type=float, default=0.9, help="create_scene's scale_factor: the file is size / scale")
-    p.add_argument("--batch", type=int, default=8)
+    p.add_argument("--batch", type=int, default=16)
     p.add_argument("--out", default="", help="animation file (default: none written, frames are hashed only)")
     p.add_argument("--hash", action="store_true", help="hash the gathered frames at sizes without a stored reference hash too")
     p.add_argument("--backend", default="nccl")
