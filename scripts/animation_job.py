@@ -28,7 +28,7 @@ def parse(argv):
     p.add_argument("--width", type=int, default=720)
     p.add_argument("--height", type=int, default=540)
     p.add_argument("--scale", type=float, default=0.9, help="create_scene's scale_factor: the file is size / scale")
-    p.add_argument("--batch", type=int, default=16)
+    p.add_argument("--batch", type=int, default=0, help="frames per launch and gather message; 0: up to 16, but at least two messages per rank so that one travels while the next renders")
     p.add_argument("--out", default="", help="animation file (default: none written, frames are hashed only)")
     p.add_argument("--hash", action="store_true", help="hash the gathered frames at sizes without a stored reference hash too")
     p.add_argument("--backend", default="nccl")
@@ -60,11 +60,12 @@ def main():
     scene = demo.DemoScene(local)
     ctx = scene.ctx
     ctx.set_option("timing", 0)
-    W, H, NF, B = a.width, a.height, demo.N_FRAMES, a.batch
+    W, H, NF = a.width, a.height, demo.N_FRAMES
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)                      # kernels, gathers and the upscale are ordered by this stream
     mine = sharding.frames_for_rank(NF, rank, world)
     longest = (NF + world - 1) // world
+    B = a.batch if a.batch > 0 else max(1, min(16, (longest + 1) // 2))
     n_batches = (longest + B - 1) // B
     bufs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(min(n_batches, 4))]
     gold = None
