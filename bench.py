@@ -60,7 +60,9 @@ def parse(argv=None):
     p.add_argument("--warmup", type=int, default=16)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--batch", type=int, default=FRAMES_PER_LAUNCH, help="frames per launch (and per gather message for N > 1)")
+    p.add_argument("--batch", type=int, default=0,
+                   help="frames per launch (and per gather message for N > 1); 0: FRAMES_PER_LAUNCH on one GPU, half of it on several "
+                        "(shorter messages: more of the gather travels behind the next launch)")
     p.add_argument("--block", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--verbose", action="store_true", help="phase markers on stderr")
@@ -176,6 +178,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     a.gpus = world
+    if a.batch <= 0:
+        a.batch = FRAMES_PER_LAUNCH if world == 1 else FRAMES_PER_LAUNCH // 2
     rehearse = a.rehearse_cpu
     if rehearse:
         a.backend = "gloo"
