@@ -387,12 +387,14 @@ def main():
                 pmc = json.load(open(PMC_PROFILE))
                 hbm = pmc.get("hbm_bytes_per_launch")
                 if hbm:
-                    hbm = int(hbm * a.batch / float(pmc.get("frames_per_launch", 8)))      # the counter pass's launches may hold fewer frames
+                    # per frame from the counter pass, times the mean number of frames in this run's launches
+                    hbm = int(hbm / float(pmc.get("frames_per_launch", 8)) * float(np.mean([len(fr) for fr in batches])))
                 roof["traffic"] = hbm
                 if hbm:
                     roof["hbm_frac"] = round(hbm / secs / 1e9 / HBM_PEAK_GBS, 5)
-                roof["traffic_source"] = ("profiles/%s: FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per %s launch of %d frames, separate "
-                                          "--pmc pass, not the timed launches" % (os.path.basename(PMC_PROFILE), pmc.get("kernel"), a.batch))
+                roof["traffic_source"] = ("profiles/%s: FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per %s launch (scaled to this run's mean "
+                                          "of %.1f frames per launch), separate --pmc pass, not the timed launches"
+                                          % (os.path.basename(PMC_PROFILE), pmc.get("kernel"), float(np.mean([len(fr) for fr in batches]))))
                 roof["valu_issue_utilisation_pmc"] = pmc.get("valu_issue_utilisation")
                 roof["valu_lane_utilisation_pmc"] = pmc.get("valu_lane_utilisation")
                 roof["vector_memory_path_busy_pmc"] = pmc.get("ta_busy")          # TA_TA_BUSY over the 256 CUs: the next limit after issue
