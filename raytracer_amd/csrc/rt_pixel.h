@@ -195,14 +195,17 @@ struct Query {
 };
 
 // Tests the triangles of one leaf (bvh.c:89-103).  Returns true when an any-hit query may stop.
-// Triangles are fetched LB at a time before any of them is tested, so that a leaf pays one
-// memory round trip per batch instead of one per triangle (at 12 registers per triangle held).
+// Triangles are fetched LB at a time before any of them is tested (one memory round trip per batch, at ten registers per
+// triangle held).
 template <bool ANY, bool COUNT, bool FULL, uint32_t LB, class Nodes>
 RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, F3 d, Query& q, Work& work) {
     constexpr bool CULL = !FULL && !ANY;
     const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
-    // the tests of one batch of fetched triangles; returns true when an any-hit query may stop
-    auto batch = [&](const TriRec (&T)[LB], uint32_t i0, uint32_t n) {
+    for (uint32_t i0 = 0; i0 < count; i0 += LB) {
+        TriRec T[LB];                                          // registers: every index below is a constant
+        const uint32_t n = count - i0 < LB ? count - i0 : LB;
+        RT_UNROLL
+        for (uint32_t k = 0; k < LB; k++) T[k] = nodes.tri(M, first + i0 + (k < n ? k : 0));
         RT_UNROLL
         for (uint32_t k = 0; k < LB; k++) {
             if (k >= n) continue;
@@ -220,14 +223,6 @@ RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, 
                 if (CULL && t < q.bound) q.limit = cull_limit(t);
             }
         }
-        return false;
-    };
-    for (uint32_t i0 = 0; i0 < count; i0 += LB) {
-        TriRec T[LB];                                          // registers: every index below is a constant
-        const uint32_t n = count - i0 < LB ? count - i0 : LB;
-        RT_UNROLL
-        for (uint32_t k = 0; k < LB; k++) T[k] = nodes.tri(M, first + i0 + (k < n ? k : 0));
-        if (batch(T, i0, n)) return true;
     }
     return false;
 }
