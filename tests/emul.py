@@ -72,10 +72,19 @@ def lib():
         L.emul_keep_hierarchy.argtypes = [vp, i32]
         L.emul_keep_hierarchy.restype = None
         L.emul_hierarchy_reused.argtypes = [vp]
+        L.emul_regroup_routes_agree.argtypes = [vp, i32, vp, i32]
         L.emul_work_plane.argtypes = [vp, vp]
         L.emul_work_plane.restype = None
         _lib = L
     return _lib
+
+
+def regroup_routes_agree(tris, nodes):
+    """0: a mesh packed with its second tree equals the same mesh packed without and regrouped afterwards (the route of meshes
+    packed on the device); 2: no second tree either way."""
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 24)
+    nodes = np.ascontiguousarray(nodes)
+    return lib().emul_regroup_routes_agree(tris.ctypes.data, tris.shape[0], nodes.ctypes.data, nodes.shape[0])
 
 
 def upscale(rgb, scaled_width, scaled_height, rows=8):

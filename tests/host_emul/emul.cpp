@@ -56,6 +56,21 @@ void emul_keep_hierarchy(void* s, int on) { ((EmulScene*)s)->keep_hierarchy = on
 int emul_hierarchy_reused(void* s) { return ((EmulScene*)s)->hierarchy_reused; }
 void emul_set_regroup(void* s, int on) { ((EmulScene*)s)->regroup = on != 0; }   // for meshes added afterwards
 
+// Packs a mesh twice -- with the second tree built by run(), and with only the reference's tree followed by
+// Packer::regroup_packed (the route of meshes packed on the device) -- and returns 0 when both give the same records, root
+// references and depth; 1 when they differ; -1 when the mesh cannot be packed; 2 when neither route built a second tree.
+int emul_regroup_routes_agree(const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes) {
+    std::string err;
+    PackedMesh a, b;
+    if (Packer(tris, n_tris, nodes, n_nodes, a, true).run(err) != RT_OK) return -1;
+    if (Packer(tris, n_tris, nodes, n_nodes, b, false).run(err) != RT_OK) return -1;
+    const bool done = Packer::regroup_packed(b);
+    const bool had = a.root_ref != a.ref_root || a.tree_pairs != (uint32_t)a.pairs.size();
+    if (!done && !had) return 2;
+    if (a.pairs.size() != b.pairs.size() || a.root_ref != b.root_ref || a.ref_root != b.ref_root || a.tree_pairs != b.tree_pairs || a.depth != b.depth) return 1;
+    return memcmp(a.pairs.data(), b.pairs.data(), a.pairs.size() * sizeof(PairNode)) == 0 ? 0 : 1;
+}
+
 int emul_mesh_add(void* sp, const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes,
                   const uint8_t* rgba, int32_t tw, int32_t th) {
     EmulScene* s = (EmulScene*)sp;

@@ -573,3 +573,20 @@ def test_flat_meshes_entered_through_their_grid_give_the_reference_frame(po):
         if (want.hit_id >= 0).mean() > 0.2:
             saved.append(counts[True] / counts[False])
     assert len(saved) >= 6 and np.median(saved) < 0.9, saved
+
+
+def test_second_tree_is_the_same_whether_built_while_packing_or_afterwards(meshes):
+    """Meshes packed on the device get their surface-area-split tree from the packed reference tree afterwards
+    (Packer::regroup_packed); it must be the tree run() builds while packing: same records, same roots, same depth."""
+    for m in meshes:
+        assert emul.regroup_routes_agree(m.tris, m.nodes) == 0
+    # a soup large enough for the threaded part of the recursion (ranges above 65 536 leaves), and tiny ones
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(5)
+    for n, want in ((300_000, 0), (40, 0), (9, 2), (1, 2)):
+        c = rng.uniform(-20, 20, (n, 1, 3)).astype(np.float32)
+        soup = np.zeros((n, 24), np.float32)
+        soup[:, 0:9] = (c + rng.normal(size=(n, 3, 3)).astype(np.float32) * 0.2).reshape(n, 9)
+        soup[:, 17] = 1.0; soup[:, 20] = 1.0; soup[:, 23] = 1.0
+        tris, nodes = po.build_bvh(soup)
+        assert emul.regroup_routes_agree(tris, nodes) == want, n
