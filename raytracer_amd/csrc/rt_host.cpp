@@ -5,7 +5,6 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <algorithm>
 #include <new>
 #include <string>
 #include <utility>
@@ -50,15 +49,6 @@ struct InstanceCache {
     float root_min[3], root_max[3];
     MeshArgs placed;
     InstanceBox box;
-    // binned rendering: screen rectangles in tiles, valid for the view / the scene bounds they were computed for
-    int32_t rect[4], srect[4];
-    uint64_t rect_view = 0, srect_view = 0, srect_bounds = 0;
-};
-
-// What the screen rectangles of an instance depend on besides its own placement.
-struct ViewKey {
-    float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3], aspect, scale, light_dir[3];
-    int32_t width, height;
 };
 
 void copy_placement(const MeshArgs& from, MeshArgs& to) {
@@ -144,35 +134,6 @@ struct rt_ctx {
     int fast = 0;                  // 1: rt_render_frame / rt_render_frames / strips run the fast build of the kernels (not bit-exact)
     int instanced_wave = 0;        // rt_render_frame_instanced: 0 = one lane per pixel, nested loops (faster); 1..8 = the per-wavefront scheduler, that many tiles per wave
     float inst_cache_cam[3] = {0, 0, 0}, inst_cache_light[3] = {0, 0, 0};
-    // rt_render_frame_instanced, instance by instance (rt_binned.hip).  Per-pixel and per-(instance, pixel) work areas are
-    // kept and grown on demand; rectangles and items travel through the staging slot of the call.
-    int instanced_binned = 0;      // 1: instance by instance whenever the rectangles are small enough (measured slower: off); 0: the nested loops
-    int binned_chunk = 0;          // tiles per wave; 0 = chosen from the total
-    unsigned long long* d_bin_keys = nullptr;
-    unsigned long long* d_bin_near = nullptr;
-    BinPixel* d_bin_pixels = nullptr;
-    uint8_t* d_bin_dark = nullptr;
-    size_t bin_pixel_cap = 0;
-    BinHit* d_bin_hits = nullptr;
-    uint32_t* d_bin_bucket = nullptr;
-    size_t bin_hit_cap = 0;
-    uint32_t* d_bin_sbucket = nullptr;
-    size_t bin_shadow_cap = 0;
-    uint32_t* d_bin_counts = nullptr;
-    size_t bin_count_cap = 0;
-    uint8_t* h_bin[kInstSlots] = {};
-    uint8_t* d_bin[kInstSlots] = {};
-    size_t bin_bytes[kInstSlots] = {};
-    hipEvent_t bin_done = nullptr;           // end of the last binned frame: the next one (on any stream) starts after it
-    bool bin_used = false;
-    ViewKey bin_view = {};
-    uint64_t bin_view_stamp = 0, bin_bounds_stamp = 0;
-    double bin_lo[3] = {0, 0, 0}, bin_hi[3] = {0, 0, 0};      // scene bounds the shadow rectangles were computed for
-    std::vector<uint32_t> bin_order;         // instances front to back, as of the last change of view or of the set of non-empty entries
-    std::vector<uint32_t> bin_order_ids;     // that set
-    uint64_t bin_order_view = 0;
-    int last_instanced_path = 0;             // 0 nested loops, 1 binned (what the last rt_render_frame_instanced ran)
-    int last_bin_cam_tiles = 0, last_bin_shadow_tiles = 0, last_bin_items = 0;      // of the last plan (also of one that was turned down)
     float build_ms = 0.0f;         // last rt_bvh_build_device
     int build_levels = 0, build_launches = 0;
     std::string err;
@@ -472,7 +433,6 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_batch, batch_bytes);
     for (int i = 0; i < kBatchSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->batch_done[i], hipEventDisableTiming);
     for (int i = 0; i < kInstSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->inst_done[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->bin_done, hipEventDisableTiming);
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) { ctx->cfg.queue = ctx->d_queue; ctx->cfg.n_cus = cus > 0 ? cus : 256; }
@@ -511,19 +471,6 @@ int rt_ctx_destroy(rt_ctx* ctx) {
         if (ctx->h_inst[i]) (void)hipHostFree(ctx->h_inst[i]);
         if (ctx->d_inst[i]) (void)hipFree(ctx->d_inst[i]);
     }
-    if (ctx->bin_done) { if (ctx->bin_used) (void)hipEventSynchronize(ctx->bin_done); (void)hipEventDestroy(ctx->bin_done); }
-    for (int i = 0; i < kInstSlots; i++) {
-        if (ctx->h_bin[i]) (void)hipHostFree(ctx->h_bin[i]);
-        if (ctx->d_bin[i]) (void)hipFree(ctx->d_bin[i]);
-    }
-    if (ctx->d_bin_keys) (void)hipFree(ctx->d_bin_keys);
-    if (ctx->d_bin_near) (void)hipFree(ctx->d_bin_near);
-    if (ctx->d_bin_pixels) (void)hipFree(ctx->d_bin_pixels);
-    if (ctx->d_bin_dark) (void)hipFree(ctx->d_bin_dark);
-    if (ctx->d_bin_hits) (void)hipFree(ctx->d_bin_hits);
-    if (ctx->d_bin_bucket) (void)hipFree(ctx->d_bin_bucket);
-    if (ctx->d_bin_sbucket) (void)hipFree(ctx->d_bin_sbucket);
-    if (ctx->d_bin_counts) (void)hipFree(ctx->d_bin_counts);
     for (int i = 0; i < kRingSlots; i++) {
         if (ctx->ring_stream[i]) { (void)hipStreamSynchronize(ctx->ring_stream[i]); (void)hipStreamDestroy(ctx->ring_stream[i]); }
         if (ctx->ring_done[i]) (void)hipEventDestroy(ctx->ring_done[i]);
@@ -995,126 +942,6 @@ int rt_render_frame_sampled_strips(rt_ctx* ctx, const rt_camera* camera, const r
                                strip_offset, flags, d_rgb, d_hit_id, stream);
 }
 
-namespace {
-
-// What a binned frame needs beyond the instances' constants: their screen rectangles and the waves' work items.
-struct BinPlan {
-    std::vector<BinRect> rects;      // per list entry
-    std::vector<BinItem> items;      // camera-ray items, then shadow items
-    uint32_t n_items = 0, n_shadow_items = 0;
-    size_t hit_slots = 0, shadow_slots = 0;
-};
-
-// Rectangles (kept per instance while view, placement and scene bounds stay), front-to-back order, items.  Returns false
-// when the rectangles cover so much of the frame that instance-by-instance rendering would test far more pixels than the
-// hierarchy proposes (many instances around or behind the camera, a light so flat that shadows sweep the whole frame):
-// the nested loops render such a frame.
-bool plan_binned(rt_ctx* ctx, const FrameArgs& A, const rt_instance* instances, const MeshArgs* inst, int32_t n_instances,
-                 const std::vector<uint32_t>& ids, BinPlan& P) {
-    ViewKey v;
-    memset(&v, 0, sizeof(v));
-    memcpy(v.cam_pos, A.cam_pos, 12); memcpy(v.cam_right, A.cam_right, 12); memcpy(v.cam_up, A.cam_up, 12); memcpy(v.cam_fwd, A.cam_fwd, 12);
-    v.aspect = A.aspect; v.scale = A.scale; memcpy(v.light_dir, A.light_dir, 12); v.width = A.width; v.height = A.height;
-    if (ctx->bin_view_stamp == 0 || memcmp(&v, &ctx->bin_view, sizeof(v)) != 0) { ctx->bin_view = v; ctx->bin_view_stamp++; }
-    const uint64_t view = ctx->bin_view_stamp;
-
-    // Bounds of the scene for the shadow rectangles: any box that holds every instance will do (a larger one only widens the
-    // rectangles), so the one in use is kept while the instances stay inside it and it is not more than twice too large --
-    // a mesh that moves about inside the scene does not invalidate the rectangles of all the others.
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (uint32_t i : ids) {
-        const InstanceBox& b = ctx->inst_cache[i].box;
-        for (int k = 0; k < 3; k++) { lo[k] = b.lo[k] < lo[k] ? b.lo[k] : lo[k]; hi[k] = b.hi[k] > hi[k] ? b.hi[k] : hi[k]; }
-    }
-    bool keep = ctx->bin_bounds_stamp != 0;
-    for (int k = 0; k < 3 && keep; k++) {
-        const double ext = hi[k] - lo[k], kept = ctx->bin_hi[k] - ctx->bin_lo[k];
-        keep = lo[k] >= ctx->bin_lo[k] && hi[k] <= ctx->bin_hi[k] && kept <= 2.0 * ext + 1.0;
-    }
-    if (!keep) {
-        for (int k = 0; k < 3; k++) {
-            const double pad = 0.05 * (hi[k] - lo[k]) + 1e-3;
-            ctx->bin_lo[k] = lo[k] - pad; ctx->bin_hi[k] = hi[k] + pad;
-        }
-        ctx->bin_bounds_stamp++;
-    }
-    const uint64_t bounds = ctx->bin_bounds_stamp;
-
-    const uint64_t frame_tiles = (uint64_t)((A.width + 7) / 8) * (uint64_t)((A.height + 7) / 8);
-    uint64_t cam_tiles = 0, shadow_tiles = 0;
-    BinRect none;
-    memset(&none, 0, sizeof(none));
-    P.rects.assign((size_t)n_instances, none);
-    for (uint32_t i : ids) {
-        InstanceCache& c = ctx->inst_cache[i];
-        if (c.rect_view != view) {
-            instance_screen_rect(instances[i].transform, inst[i].root_min, inst[i].root_max, A, c.rect);
-            c.rect_view = view;
-        }
-        if (c.srect_view != view || c.srect_bounds != bounds) {
-            instance_shadow_rect(instances[i].transform, inst[i].root_min, inst[i].root_max, ctx->bin_lo, ctx->bin_hi, A, c.srect);
-            c.srect_view = view; c.srect_bounds = bounds;
-        }
-        BinRect& r = P.rects[i];
-        if (c.rect[2] > c.rect[0] && c.rect[3] > c.rect[1]) { r.x0 = c.rect[0]; r.y0 = c.rect[1]; r.x1 = c.rect[2]; r.y1 = c.rect[3]; }
-        if (c.srect[2] > c.srect[0] && c.srect[3] > c.srect[1]) { r.sx0 = c.srect[0]; r.sy0 = c.srect[1]; r.sx1 = c.srect[2]; r.sy1 = c.srect[3]; }
-        const uint64_t t = (uint64_t)(r.x1 - r.x0) * (uint64_t)(r.y1 - r.y0);
-        if (cam_tiles * 64 + t * 64 >= 0xFFFF0000ull) return false;
-        r.slot0 = (uint32_t)(cam_tiles * 64);
-        cam_tiles += t;
-        const uint64_t st = (uint64_t)(r.sx1 - r.sx0) * (uint64_t)(r.sy1 - r.sy0);
-        if (shadow_tiles * 64 + st * 64 >= 0xFFFF0000ull) return false;
-        r.sslot0 = (uint32_t)(shadow_tiles * 64);
-        shadow_tiles += st;
-    }
-    ctx->last_bin_cam_tiles = (int)(cam_tiles > 0x7FFFFFFF ? 0x7FFFFFFF : cam_tiles);
-    ctx->last_bin_shadow_tiles = (int)(shadow_tiles > 0x7FFFFFFF ? 0x7FFFFFFF : shadow_tiles);
-    if (cam_tiles > 16 * frame_tiles + 4 * ids.size() || shadow_tiles > 32 * frame_tiles + 4 * ids.size()) return false;
-    P.hit_slots = (size_t)cam_tiles * 64;
-    P.shadow_slots = (size_t)shadow_tiles * 64;
-
-    // front to back by the distance of the box centres: the order only decides which waves start first
-    if (ctx->bin_order_view != view || ctx->bin_order_ids != ids) {
-        std::vector<std::pair<float, uint32_t>> keyed;
-        keyed.reserve(ids.size());
-        for (uint32_t i : ids) {
-            const InstanceBox& b = ctx->inst_cache[i].box;
-            float d2 = 0.0f;
-            for (int k = 0; k < 3; k++) { const float d = 0.5f * (b.lo[k] + b.hi[k]) - A.cam_pos[k]; d2 += d * d; }
-            keyed.emplace_back(d2, i);
-        }
-        std::sort(keyed.begin(), keyed.end());
-        ctx->bin_order.resize(ids.size());
-        for (size_t k = 0; k < keyed.size(); k++) ctx->bin_order[k] = keyed[k].second;
-        ctx->bin_order_view = view;
-        ctx->bin_order_ids = ids;
-    }
-
-    auto chunk_for = [&](uint64_t tiles) {
-        if (ctx->binned_chunk > 0) return (uint32_t)ctx->binned_chunk;
-        const uint64_t c = tiles / 16384;
-        return (uint32_t)(c < 4 ? 4 : (c > 64 ? 64 : c));
-    };
-    P.items.clear();
-    const uint32_t cam_chunk = chunk_for(cam_tiles), shadow_chunk = chunk_for(shadow_tiles);
-    for (uint32_t i : ctx->bin_order) {
-        const BinRect& r = P.rects[i];
-        const uint32_t t = (uint32_t)((r.x1 - r.x0) * (r.y1 - r.y0));
-        for (uint32_t first = 0; first < t; first += cam_chunk) P.items.push_back(BinItem{i, first, t - first < cam_chunk ? t - first : cam_chunk, 0});
-    }
-    P.n_items = (uint32_t)P.items.size();
-    for (uint32_t i : ctx->bin_order) {
-        const BinRect& r = P.rects[i];
-        const uint32_t t = (uint32_t)((r.sx1 - r.sx0) * (r.sy1 - r.sy0));
-        for (uint32_t first = 0; first < t; first += shadow_chunk) P.items.push_back(BinItem{i, first, t - first < shadow_chunk ? t - first : shadow_chunk, 0});
-    }
-    P.n_shadow_items = (uint32_t)P.items.size() - P.n_items;
-    ctx->last_bin_items = (int)P.items.size();
-    return true;
-}
-
-}  // namespace
-
 int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_light* light, const rt_instance* instances, int32_t n_instances,
                               int32_t width, int32_t height, uint32_t flags, void* d_rgb, void* d_hit_instance, void* d_hit_tri,
                               void* d_hit_t, void* d_shadow, void* stream) {
@@ -1173,97 +1000,11 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
         } else {
             fill_placement(instances[i].transform, A, inst[i]);
             c.valid = true; c.transform = instances[i].transform; c.placed = inst[i];
-            c.rect_view = 0; c.srect_view = 0;
             memcpy(c.root_min, inst[i].root_min, 12); memcpy(c.root_max, inst[i].root_max, 12);
             c.box = instance_box(instances[i].transform, inst[i].root_min, inst[i].root_max);
         }
         if (!inst[i].empty) { boxes.push_back(c.box); ids.push_back((uint32_t)i); }
     }
-    // ---- instance by instance (rt_binned.hip), when the instances' screen rectangles are small enough for it to pay ----
-    BinPlan plan;
-    const bool binned = ctx->instanced_binned && !ctx->instanced_wave && !(flags & RT_FLAG_COUNT_WORK) && width <= 65535 && height <= 65535 &&
-                        !ids.empty() && plan_binned(ctx, A, instances, inst, n_instances, ids, plan);
-    ctx->last_instanced_path = binned ? 1 : 0;
-    if (binned) {
-        const size_t pixels = (size_t)width * (size_t)height;
-        if (pixels > ctx->bin_pixel_cap || plan.hit_slots > ctx->bin_hit_cap || plan.shadow_slots > ctx->bin_shadow_cap || 3 * n > ctx->bin_count_cap) {
-            if (ctx->bin_used) RT_HIP(ctx, hipEventSynchronize(ctx->bin_done));
-            if (pixels > ctx->bin_pixel_cap) {
-                if (ctx->d_bin_keys) (void)hipFree(ctx->d_bin_keys);
-                if (ctx->d_bin_near) (void)hipFree(ctx->d_bin_near);
-                if (ctx->d_bin_pixels) (void)hipFree(ctx->d_bin_pixels);
-                if (ctx->d_bin_dark) (void)hipFree(ctx->d_bin_dark);
-                ctx->d_bin_keys = nullptr; ctx->d_bin_near = nullptr; ctx->d_bin_pixels = nullptr; ctx->d_bin_dark = nullptr; ctx->bin_pixel_cap = 0;
-                RT_HIP(ctx, hipMalloc((void**)&ctx->d_bin_keys, pixels * sizeof(unsigned long long)));
-                RT_HIP(ctx, hipMalloc((void**)&ctx->d_bin_near, pixels * sizeof(unsigned long long)));
-                RT_HIP(ctx, hipMalloc((void**)&ctx->d_bin_pixels, pixels * sizeof(BinPixel)));
-                RT_HIP(ctx, hipMalloc((void**)&ctx->d_bin_dark, pixels));
-                ctx->bin_pixel_cap = pixels;
-            }
-            if (plan.hit_slots > ctx->bin_hit_cap) {
-                if (ctx->d_bin_hits) (void)hipFree(ctx->d_bin_hits);
-                if (ctx->d_bin_bucket) (void)hipFree(ctx->d_bin_bucket);
-                ctx->d_bin_hits = nullptr; ctx->d_bin_bucket = nullptr; ctx->bin_hit_cap = 0;
-                const size_t want = plan.hit_slots + plan.hit_slots / 4 + 4096;          // room for rectangles that grow a little
-                RT_HIP(ctx, hipMalloc((void**)&ctx->d_bin_hits, want * sizeof(BinHit)));
-                RT_HIP(ctx, hipMalloc((void**)&ctx->d_bin_bucket, want * sizeof(uint32_t)));
-                ctx->bin_hit_cap = want;
-            }
-            if (plan.shadow_slots > ctx->bin_shadow_cap) {
-                if (ctx->d_bin_sbucket) (void)hipFree(ctx->d_bin_sbucket);
-                ctx->d_bin_sbucket = nullptr; ctx->bin_shadow_cap = 0;
-                const size_t want = plan.shadow_slots + plan.shadow_slots / 4 + 4096;
-                RT_HIP(ctx, hipMalloc((void**)&ctx->d_bin_sbucket, want * sizeof(uint32_t)));
-                ctx->bin_shadow_cap = want;
-            }
-            if (3 * n > ctx->bin_count_cap) {
-                if (ctx->d_bin_counts) (void)hipFree(ctx->d_bin_counts);
-                ctx->d_bin_counts = nullptr; ctx->bin_count_cap = 0;
-                RT_HIP(ctx, hipMalloc((void**)&ctx->d_bin_counts, (3 * n + 3 * n / 4 + 64) * sizeof(uint32_t)));
-                ctx->bin_count_cap = 3 * n + 3 * n / 4 + 64;
-            }
-        }
-        const size_t off_items = ((size_t)n_instances * sizeof(BinRect) + 63) & ~(size_t)63;
-        const size_t bin_total = off_items + plan.items.size() * sizeof(BinItem);
-        if (bin_total > ctx->bin_bytes[slot]) {
-            if (ctx->h_bin[slot]) (void)hipHostFree(ctx->h_bin[slot]);
-            if (ctx->d_bin[slot]) (void)hipFree(ctx->d_bin[slot]);
-            ctx->h_bin[slot] = nullptr; ctx->d_bin[slot] = nullptr; ctx->bin_bytes[slot] = 0;
-            const size_t want = bin_total + bin_total / 2;
-            RT_HIP(ctx, hipHostMalloc((void**)&ctx->h_bin[slot], want, hipHostMallocDefault));
-            RT_HIP(ctx, hipMalloc((void**)&ctx->d_bin[slot], want));
-            ctx->bin_bytes[slot] = want;
-        }
-        memcpy(ctx->h_bin[slot], plan.rects.data(), (size_t)n_instances * sizeof(BinRect));
-        memcpy(ctx->h_bin[slot] + off_items, plan.items.data(), plan.items.size() * sizeof(BinItem));
-        if (ctx->bin_used) RT_HIP(ctx, hipStreamWaitEvent(s, ctx->bin_done, 0));     // the work areas are shared by all binned frames
-        RT_HIP(ctx, hipMemcpyAsync(d, h, n * sizeof(MeshArgs), hipMemcpyHostToDevice, s));
-        RT_HIP(ctx, hipMemcpyAsync(ctx->d_bin[slot], ctx->h_bin[slot], bin_total, hipMemcpyHostToDevice, s));
-        InstancedArgs I;
-        memset(&I, 0, sizeof(I));
-        I.inst = reinterpret_cast<const MeshArgs*>(d);
-        I.n_inst = (int32_t)ids.size();
-        I.tlas_root = leaf_ref(0, 0); I.tlas = nullptr;
-        BinArgs B;
-        B.rects = reinterpret_cast<const BinRect*>(ctx->d_bin[slot]);
-        B.items = reinterpret_cast<const BinItem*>(ctx->d_bin[slot] + off_items);
-        B.n_items = plan.n_items; B.n_shadow_items = plan.n_shadow_items; B.n_inst = (uint32_t)n_instances; B.pad = 0;
-        B.keys = ctx->d_bin_keys; B.nearest = ctx->d_bin_near; B.hits = ctx->d_bin_hits; B.bucket = ctx->d_bin_bucket;
-        B.sbucket = ctx->d_bin_sbucket; B.counts = ctx->d_bin_counts; B.pixels = ctx->d_bin_pixels; B.dark = ctx->d_bin_dark;
-        OutputPlanes O;
-        O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_instance; O.hit_t = (float*)d_hit_t; O.shadow = (uint8_t*)d_shadow;
-        O.counters = ctx->d_counters; O.tile_clock = nullptr;
-        if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-        hipError_t le = launch_instanced_binned(A, I, S, O, (int32_t*)d_hit_tri, B, s);
-        if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
-        if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
-        RT_HIP(ctx, hipEventRecord(ctx->inst_done[slot], s));
-        ctx->inst_used[slot] = true;
-        RT_HIP(ctx, hipEventRecord(ctx->bin_done, s));
-        ctx->bin_used = true;
-        return RT_OK;
-    }
-
     Tlas T;
     if (ctx->keep_hierarchy) (void)ctx->standing.update(boxes, ids, (size_t)n_instances, T);
     else TlasBuilder(boxes, ids, T).run();
@@ -1550,8 +1291,6 @@ int rt_set_option(rt_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "fast")) { ctx->fast = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "screen_cull")) { ctx->screen_cull = value ? 1 : 0; return RT_OK; }
     if (!strcmp(name, "instanced_wave")) { ctx->instanced_wave = value < 0 ? 0 : (value > 8 ? 8 : value); return RT_OK; }
-    if (!strcmp(name, "instanced_binned")) { ctx->instanced_binned = value != 0; return RT_OK; }
-    if (!strcmp(name, "binned_chunk")) { ctx->binned_chunk = value < 0 ? 0 : (value > 4096 ? 4096 : value); return RT_OK; }
     if (!strcmp(name, "frames_in_flight")) {
         if (value < 1 || value > kRingSlots) return fail(ctx, RT_ERR_INVALID, "frames_in_flight must be 1..8");
         const int st = rt_sync(ctx, nullptr);            // the ring is empty whenever its length changes
@@ -1585,12 +1324,6 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "frames_in_flight")) { *value = ctx->frames_in_flight; return RT_OK; }
     if (!strcmp(name, "keep_hierarchy")) { *value = ctx->keep_hierarchy; return RT_OK; }
     if (!strcmp(name, "instanced_wave")) { *value = ctx->instanced_wave; return RT_OK; }
-    if (!strcmp(name, "instanced_binned")) { *value = ctx->instanced_binned; return RT_OK; }
-    if (!strcmp(name, "binned_chunk")) { *value = ctx->binned_chunk; return RT_OK; }
-    if (!strcmp(name, "last_instanced_path")) { *value = ctx->last_instanced_path; return RT_OK; }
-    if (!strcmp(name, "last_binned_camera_tiles")) { *value = ctx->last_bin_cam_tiles; return RT_OK; }
-    if (!strcmp(name, "last_binned_shadow_tiles")) { *value = ctx->last_bin_shadow_tiles; return RT_OK; }
-    if (!strcmp(name, "last_binned_items")) { *value = ctx->last_bin_items; return RT_OK; }
     if (!strcmp(name, "fast")) { *value = ctx->fast; return RT_OK; }
     if (!strcmp(name, "screen_cull")) { *value = ctx->screen_cull; return RT_OK; }
     if (!strcmp(name, "coop")) { *value = ctx->coop; return RT_OK; }

@@ -60,15 +60,6 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
 hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const SceneArgs& S, const OutputPlanes& O, int32_t* hit_tri,
                             int tlas_entries, int block, int wave_tiles, hipStream_t stream);
 
-// The same frame rendered instance by instance (rt_binned.hip): no hierarchy; B.rects holds every instance's screen
-// rectangles in tiles (inside the frame; x1 > x0 and y1 > y0 wherever an item names the instance), B.items B.n_items
-// camera-ray items followed by B.n_shadow_items shadow items (tile ranges inside their instance's rectangle),
-// B.hits and B.bucket 64 entries per tile of every camera-ray rectangle (from BinRect::slot0), B.sbucket 64 per tile of
-// every shadow rectangle (from BinRect::sslot0), B.counts 3 x B.n_inst words, B.keys / B.nearest / B.pixels / B.dark one
-// per pixel of the frame.  Width and height at most 65535.  Launches that share these buffers must be ordered.
-hipError_t launch_instanced_binned(const FrameArgs& A, const InstancedArgs& I, const SceneArgs& S, const OutputPlanes& O, int32_t* hit_tri,
-                                   const BinArgs& B, hipStream_t stream);
-
 // Enqueues the bicubic upscale of n_frames RGB8 frames (width x height, frame f at rgb + f*frame_stride
 // bytes) to ARGB32 frames (scaled_width x scaled_height, frame f at argb + f*out_stride pixels).
 // scaled sizes must be at least 2 (the source coordinate divides by scaled-1).

@@ -159,48 +159,6 @@ struct InstancedArgs {
     float root_min[3], root_max[3];
 };
 
-// Instanced scenes rendered instance by instance ("binned", rt_binned.hip).  The hierarchy over the instances is not
-// used: every instance brings the screen rectangles outside of which its root test fails for certain (instance_screen_rect /
-// instance_shadow_rect, in 8x8-pixel tiles).  Root-test passes go over the tiles of ONE instance per wave -- the instance's
-// constants are wave-uniform -- and append the pixels that pass the exact root test to the instance's bucket; walk passes
-// take 64 consecutive entries of one bucket per wave: full waves of rays that are neighbours in the instance's own space.
-// The closest hit of a pixel over all instances is an atomic minimum over (t, list index), the reference's own rule
-// (scene.c:82: strictly closer, so the earlier entry keeps an equal t).
-struct BinRect {
-    int32_t x0, y0, x1, y1;      // camera rays: tiles {x0, y0, x1, y1} half open
-    int32_t sx0, sy0, sx1, sy1;  // shadow rays
-    uint32_t slot0;              // first hit record / bucket entry of this instance: 64 per tile of its camera-ray rectangle
-    uint32_t sslot0;             // first shadow bucket entry: 64 per tile of its shadow rectangle
-    uint32_t pad[2];
-};
-struct BinItem {                 // work of one wave: tiles (or batches of 64 bucket entries) [first, first + count) of the instance
-    uint32_t inst, first, count, pad;
-};
-struct BinHit { uint32_t tri; float u, v; };
-struct BinPixel {                // what the shadow and colour passes need of a pixel with a hit
-    float so[3];                 // shadow ray origin (scene.c:118-122)
-    float lit;                   // max(0.2, n.L): the diffuse term if nothing blocks the light (scene.c:143-144)
-    float color[3];              // texel * light colour (scene.c:148)
-    uint32_t pad;
-};
-constexpr unsigned long long kBinNoHit = ((unsigned long long)0x7149F2CAu << 32) | 0xFFFFFFFFull;   // (1e30f, no instance)
-struct BinArgs {
-    const BinRect* rects;        // per instance, list order
-    const BinItem* items;        // camera-ray items, then shadow items
-    uint32_t n_items, n_shadow_items;
-    uint32_t n_inst;             // list entries (length of rects, a third of counts)
-    uint32_t pad;
-    unsigned long long* keys;    // per pixel: float bits of the closest t << 32 | list index of its instance
-    unsigned long long* nearest; // per pixel: float bits of the smallest root-box entry distance << 32 | list index
-    BinHit* hits;                // per (instance, pixel of its rectangle)
-    uint32_t* bucket;            // per instance 64 entries per camera-ray tile: pixels (y << 16 | x) whose ray passes the root box;
-                                 // those the instance is the nearest entry of from the front, the others from the back
-    uint32_t* sbucket;           // per instance 64 entries per shadow tile: pixels whose shadow ray passes the root box
-    uint32_t* counts;            // [first | rest | shadow] x n_inst: entries in the buckets
-    BinPixel* pixels;            // per pixel
-    uint8_t* dark;               // per pixel: 0 lit, 1 blocked, 2 no hit
-};
-
 struct DeviceCounters {          // accumulated with atomics when counting is requested
     unsigned long long primary_rays, shadow_rays, slab_tests, tri_tests, hit_pixels, shadowed_pixels;
 };

@@ -688,102 +688,6 @@ inline void mesh_shadow_rect(const rt_transform& tf, const float* bmin, const fl
     (void)tiles_around(pts, 16, slack, A, rect);
 }
 
-// ---- screen rectangles that also hold for boxes beside, around and behind the camera (binned instanced frames) -----------
-// tiles_around gives up (whole frame) as soon as one point lies at or behind the camera plane.  With thousands of placed
-// meshes around the camera that would be hundreds of whole frames, so here the convex hull of the points is clipped first:
-//  * if the camera is within near_r = 64 slack + 1e-3 of the points' bounding box: whole frame;
-//  * otherwise a point of the hull (moved by up to `slack`) that an on-screen ray can meet at depth z is no farther from
-//    the camera than K z, K = sqrt(1 + (aspect scale)^2 + scale^2), and no nearer than near_r - slack, so only the part
-//    of the hull with z >= zc = (near_r - slack) / K - slack can be seen at all; that part is the hull of the points in
-//    front of the plane z = zc and of the points where segments between a point in front and a point behind cross it
-//    (all pairs: a superset of the hull's edges, every crossing point lies in the hull);
-//  * each of those points is projected and widened by its own allowance: 2 slack (1 + |s|) / z for its position, and
-//    2^-14 (1 + s_screen^2) for the rounding of an on-screen ray's direction; two pixels are added on every side.
-// No point in front of the plane: no camera ray can meet the hull, the rectangle is empty {0, 0, 0, 0}.
-inline void hull_tiles(const double (*pts)[3], int n, double slack, const FrameArgs& A, int32_t rect[4]) {
-    const int tiles_x = (A.width + 7) / 8, tiles_y = (A.full_height + 7) / 8;
-    rect[0] = 0; rect[1] = 0; rect[2] = tiles_x; rect[3] = tiles_y;
-    if (n <= 0 || n > 16) return;
-    const double AS = (double)A.aspect * A.scale, S = A.scale;
-    if (!(AS > 0) || !(S > 0) || !(AS < 1e6) || !(S < 1e6) || !(slack >= 0) || !(slack < 1e12)) return;
-    const double K = sqrt(1.0 + AS * AS + S * S), near_r = 64.0 * slack + 1e-3;
-    double c[16][3], d2 = 0.0;
-    for (int i = 0; i < 3; i++) {
-        double lo = 1e300, hi = -1e300;
-        for (int k = 0; k < n; k++) { lo = pts[k][i] < lo ? pts[k][i] : lo; hi = pts[k][i] > hi ? pts[k][i] : hi; }
-        if (!(lo == lo) || !(hi == hi) || !(lo > -1e300) || !(hi < 1e300)) return;
-        const double cam = A.cam_pos[i], d = cam < lo ? lo - cam : (cam > hi ? cam - hi : 0.0);
-        d2 += d * d;
-    }
-    if (!(d2 > near_r * near_r)) return;                                  // the camera is at the hull: every pixel may see it
-    const double zc = (near_r - slack) / K - slack;
-    if (!(zc > 3.0 * slack) || !(zc > 0)) return;                         // a view so wide that the clipping plane drowns in the slack
-    for (int k = 0; k < n; k++) {
-        double w[3];
-        for (int i = 0; i < 3; i++) w[i] = pts[k][i] - (double)A.cam_pos[i];
-        c[k][0] = w[0] * A.cam_right[0] + w[1] * A.cam_right[1] + w[2] * A.cam_right[2];
-        c[k][1] = w[0] * A.cam_up[0] + w[1] * A.cam_up[1] + w[2] * A.cam_up[2];
-        c[k][2] = w[0] * A.cam_fwd[0] + w[1] * A.cam_fwd[1] + w[2] * A.cam_fwd[2];
-    }
-    const double ang = (1.0 + AS * AS + S * S) / 16384.0;
-    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
-    bool any = false;
-    auto take = [&](double x, double y, double z) {
-        const double sx = x / z, sy = y / z;
-        const double a = fabs(sx) > fabs(sy) ? fabs(sx) : fabs(sy);
-        const double allow = 2.0 * slack * (1.0 + a) / z + ang;
-        lo[0] = sx - allow < lo[0] ? sx - allow : lo[0]; hi[0] = sx + allow > hi[0] ? sx + allow : hi[0];
-        lo[1] = sy - allow < lo[1] ? sy - allow : lo[1]; hi[1] = sy + allow > hi[1] ? sy + allow : hi[1];
-        any = true;
-    };
-    for (int k = 0; k < n; k++) {
-        if (!(c[k][2] > zc)) continue;
-        take(c[k][0], c[k][1], c[k][2]);
-        for (int j = 0; j < n; j++) {
-            if (c[j][2] > zc) continue;
-            const double f = (c[k][2] - zc) / (c[k][2] - c[j][2]);         // in (0, 1]
-            take(c[k][0] + (c[j][0] - c[k][0]) * f, c[k][1] + (c[j][1] - c[k][1]) * f, zc);
-        }
-    }
-    if (!any) { rect[0] = rect[1] = rect[2] = rect[3] = 0; return; }
-    if (!(lo[0] == lo[0]) || !(hi[0] == hi[0]) || !(lo[1] == lo[1]) || !(hi[1] == hi[1])) return;
-    const double kx = 0.5 * A.width / AS, ky = 0.5 * A.full_height / S;
-    const double px_lo = lo[0] * kx + 0.5 * A.width - 0.5 - 2.0, px_hi = hi[0] * kx + 0.5 * A.width - 0.5 + 2.0;
-    const double py_lo = 0.5 * A.full_height - hi[1] * ky - 0.5 - 2.0, py_hi = 0.5 * A.full_height - lo[1] * ky - 0.5 + 2.0;
-    auto tile_lo = [](double v, int m) { const double t = floor(v / 8.0); return t < 0 ? 0 : (t > m ? m : (int)t); };
-    auto tile_hi = [](double v, int m) { const double t = floor(v / 8.0) + 1.0; return t < 0 ? 0 : (t > m ? m : (int)t); };
-    rect[0] = tile_lo(px_lo, tiles_x); rect[1] = tile_lo(py_lo, tiles_y);
-    rect[2] = tile_hi(px_hi, tiles_x); rect[3] = tile_hi(py_hi, tiles_y);
-    if (rect[2] <= rect[0] || rect[3] <= rect[1]) rect[0] = rect[1] = rect[2] = rect[3] = 0;
-}
-
-// mesh_screen_rect / mesh_shadow_rect with the clipped hull: the same points, the same slack.
-inline void instance_screen_rect(const rt_transform& tf, const float* bmin, const float* bmax, const FrameArgs& A, int32_t rect[4]) {
-    const WorldBox b = world_box(tf, bmin, bmax);
-    hull_tiles(b.corner, 8, placement_magnitude(tf, bmin, bmax, A) * (1.0 / 262144.0), A, rect);
-}
-inline void instance_shadow_rect(const rt_transform& tf, const float* bmin, const float* bmax, const double scene_lo[3], const double scene_hi[3],
-                                 const FrameArgs& A, int32_t rect[4]) {
-    const int tiles_x = (A.width + 7) / 8, tiles_y = (A.full_height + 7) / 8;
-    rect[0] = 0; rect[1] = 0; rect[2] = tiles_x; rect[3] = tiles_y;
-    const WorldBox b = world_box(tf, bmin, bmax);
-    double mag = placement_magnitude(tf, bmin, bmax, A);
-    for (int i = 0; i < 3; i++) mag += (fabs(scene_lo[i]) > fabs(scene_hi[i]) ? fabs(scene_lo[i]) : fabs(scene_hi[i]));
-    const double slack = mag * (1.0 / 262144.0) + 0.002;
-    double s_max = 1e300;
-    for (int i = 0; i < 3; i++) {
-        const double L = A.light_dir[i];
-        if (L > 0) { const double s = (b.hi[i] + slack - (scene_lo[i] - slack)) / L; s_max = s < s_max ? s : s_max; }
-        else if (L < 0) { const double s = (scene_hi[i] + slack - (b.lo[i] - slack)) / -L; s_max = s < s_max ? s : s_max; }
-    }
-    if (!(s_max < 1e9)) return;
-    if (!(s_max > 0)) s_max = 0;
-    double pts[16][3];
-    for (int c = 0; c < 16; c++)
-        for (int i = 0; i < 3; i++) pts[c][i] = b.corner[c & 7][i] - (c < 8 ? 0.0 : s_max) * (double)A.light_dir[i];
-    hull_tiles(pts, 16, slack, A, rect);
-}
-
 // ---- hierarchy over placed instances (never used for results, only to propose instances) ----------
 // World-space box of an instance, padded so that float rounding in the world-space slab test can never
 // reject a ray that the exact test in the instance's own space would accept: 1e-4 of the box's extent

@@ -27,8 +27,6 @@ def main():
     p.add_argument("--frames", default="0,45")
     p.add_argument("--reps", type=int, default=5)
     p.add_argument("--wave", type=int, default=-1, help="option instanced_wave: tiles per wave of the per-wavefront scheduler, 0 = nested loops per lane")
-    p.add_argument("--binned", type=int, default=-1, help="option instanced_binned: 1 = instance by instance where it pays, 0 = always the nested loops")
-    p.add_argument("--chunk", type=int, default=-1, help="option binned_chunk: tiles per wave of the binned passes, 0 = chosen from the total")
     p.add_argument("--no-rebuild", action="store_true", help="move the drone by its transform only (no per-frame BVH rebuild)")
     a = p.parse_args()
     from raytracer_amd import capi, demo
@@ -38,10 +36,6 @@ def main():
     ctx = scene.ctx
     if a.wave >= 0:
         ctx.set_option("instanced_wave", a.wave)
-    if a.binned >= 0:
-        ctx.set_option("instanced_binned", a.binned)
-    if a.chunk >= 0:
-        ctx.set_option("binned_chunk", a.chunk)
     rng = np.random.default_rng(3)
     ids, tfs = [0, 2], [None, capi.Transform()]
     half = (a.side - 1) / 2.0
@@ -101,11 +95,7 @@ def main():
            "config": {"workload": f"{W}x{H}, {len(ids)} instances ({placed} placed triangles): {a.side}x{a.side} treasures + ground + drone, "
                                   "hierarchy over the instances rebuilt on the host per frame"
                                   + ("" if a.no_rebuild else "; the drone's vertices rewritten, its BVH rebuilt and re-uploaded per frame")},
-           "dtype": "f32", "instanced_wave": ctx.get_option("instanced_wave"), "instanced_binned": ctx.get_option("instanced_binned"),
-           "binned_path_taken": ctx.get_option("last_instanced_path"),
-           "binned_plan": {"camera_tiles": ctx.get_option("last_binned_camera_tiles"), "shadow_tiles": ctx.get_option("last_binned_shadow_tiles"),
-                           "items": ctx.get_option("last_binned_items"), "frame_tiles": ((W + 7) // 8) * ((H + 7) // 8)},
-           "frames": rows}
+           "dtype": "f32", "instanced_wave": ctx.get_option("instanced_wave"), "frames": rows}
     print(json.dumps(out), flush=True)
     scene.close()
 

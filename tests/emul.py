@@ -59,10 +59,6 @@ def lib():
         L.emul_screen_rect.restype = None
         L.emul_shadow_rect.argtypes = [C.POINTER(Transform), vp, vp, vp, vp, C.POINTER(Camera), C.POINTER(Light), i32, i32, vp]
         L.emul_shadow_rect.restype = None
-        L.emul_instance_screen_rect.argtypes = L.emul_screen_rect.argtypes
-        L.emul_instance_screen_rect.restype = None
-        L.emul_instance_shadow_rect.argtypes = L.emul_shadow_rect.argtypes
-        L.emul_instance_shadow_rect.restype = None
         L.emul_sample_offset.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_float)] * 2
         L.emul_sample_offset.restype = None
         L.emul_render_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, C.c_uint32,
@@ -98,29 +94,26 @@ def upscale(rgb, scaled_width, scaled_height, rows=8):
     return out
 
 
-def screen_rect(tf, bmin, bmax, cam, light, width, height, clipped=False):
-    """mesh_screen_rect: tiles {x0, y0, x1, y1} outside of which camera rays cannot pass the placed box.
-    clipped: instance_screen_rect, the form binned instanced frames use (hull clipped in front of the camera)."""
+def screen_rect(tf, bmin, bmax, cam, light, width, height):
+    """mesh_screen_rect: tiles {x0, y0, x1, y1} outside of which camera rays cannot pass the placed box."""
     lo = np.ascontiguousarray(bmin, np.float32)
     hi = np.ascontiguousarray(bmax, np.float32)
     out = np.zeros(4, np.int32)
     t, c, l = conv(tf, Transform), conv(cam, Camera), conv(light, Light)
-    fn = lib().emul_instance_screen_rect if clipped else lib().emul_screen_rect
-    fn(C.byref(t), lo.ctypes.data, hi.ctypes.data, C.byref(c), C.byref(l), width, height, out.ctypes.data)
+    lib().emul_screen_rect(C.byref(t), lo.ctypes.data, hi.ctypes.data, C.byref(c), C.byref(l), width, height, out.ctypes.data)
     return [int(v) for v in out]
 
 
-def shadow_rect(tf, bmin, bmax, scene_lo, scene_hi, cam, light, width, height, clipped=False):
-    """mesh_shadow_rect: tiles outside of which no point of the scene's bounds sends a shadow ray through the placed box.
-    clipped: instance_shadow_rect."""
+def shadow_rect(tf, bmin, bmax, scene_lo, scene_hi, cam, light, width, height):
+    """mesh_shadow_rect: tiles outside of which no point of the scene's bounds sends a shadow ray through the placed box."""
     lo = np.ascontiguousarray(bmin, np.float32)
     hi = np.ascontiguousarray(bmax, np.float32)
     slo = np.ascontiguousarray(scene_lo, np.float64)
     shi = np.ascontiguousarray(scene_hi, np.float64)
     out = np.zeros(4, np.int32)
     t, c, l = conv(tf, Transform), conv(cam, Camera), conv(light, Light)
-    fn = lib().emul_instance_shadow_rect if clipped else lib().emul_shadow_rect
-    fn(C.byref(t), lo.ctypes.data, hi.ctypes.data, slo.ctypes.data, shi.ctypes.data, C.byref(c), C.byref(l), width, height, out.ctypes.data)
+    lib().emul_shadow_rect(C.byref(t), lo.ctypes.data, hi.ctypes.data, slo.ctypes.data, shi.ctypes.data, C.byref(c), C.byref(l),
+                           width, height, out.ctypes.data)
     return [int(v) for v in out]
 
 

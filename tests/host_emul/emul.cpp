@@ -118,21 +118,6 @@ void emul_shadow_rect(const rt_transform* tf, const float* bmin, const float* bm
     mesh_shadow_rect(*tf, bmin, bmax, scene_lo, scene_hi, A, rect4);
 }
 
-// The same rectangles as binned instanced frames compute them (hull clipped in front of the camera: instance_screen_rect /
-// instance_shadow_rect); an empty rectangle is {0, 0, 0, 0}.
-void emul_instance_screen_rect(const rt_transform* tf, const float* bmin, const float* bmax, const rt_camera* cam, const rt_light* light,
-                               int32_t width, int32_t height, int32_t* rect4) {
-    FrameArgs A; memset(&A, 0, sizeof A);
-    fill_camera(*cam, *light, width, height, A);
-    instance_screen_rect(*tf, bmin, bmax, A, rect4);
-}
-void emul_instance_shadow_rect(const rt_transform* tf, const float* bmin, const float* bmax, const double* scene_lo, const double* scene_hi,
-                               const rt_camera* cam, const rt_light* light, int32_t width, int32_t height, int32_t* rect4) {
-    FrameArgs A; memset(&A, 0, sizeof A);
-    fill_camera(*cam, *light, width, height, A);
-    instance_shadow_rect(*tf, bmin, bmax, scene_lo, scene_hi, A, rect4);
-}
-
 // Per-frame constants as the product computes them: inv rows 0..3 (16 floats) and nrm (9 floats).
 void emul_placement(const rt_transform* tf, const rt_camera* cam, const rt_light* light, float* inv16, float* nrm9,
                     float* cam_o3, float* lit_d3, uint32_t* w_mode) {

@@ -371,12 +371,8 @@ def test_culling_keeps_the_reference_result_on_adversarial_scenes(po):
 
 
 # ------------------------------------------------------------------------------ meshes skipped by screen rectangle
-@pytest.mark.parametrize("clipped", [False, True])
-def test_screen_rectangle_contains_every_pixel_whose_ray_passes_the_root_box(po, clipped):
-    """clipped: instance_screen_rect, which binned instanced frames use -- the box's hull is clipped in front of the camera
-    instead of giving the whole frame as soon as a corner lies behind the camera plane; every third trial of that run puts
-    the camera right beside, above or inside the box's reach.
-    mesh_screen_rect promises: outside the rectangle the reference's root test (ray.c:5-22 transform, aabb.c:33-56)
+def test_screen_rectangle_contains_every_pixel_whose_ray_passes_the_root_box(po):
+    """mesh_screen_rect promises: outside the rectangle the reference's root test (ray.c:5-22 transform, aabb.c:33-56)
     fails.  Checked pixel by pixel with the oracle's own get_camera_ray / transform_ray / ray_aabb_intersect on boxes,
     placements and cameras that stress it: far from the origin, camera close to the box, narrow and wide views,
     flat boxes, a box behind or around the camera (then the rectangle must be the whole frame)."""
@@ -405,14 +401,8 @@ def test_screen_rectangle_contains_every_pixel_whose_ray_passes_the_root_box(po,
         else:
             look = centre + rng.normal(size=3) * float(half.max()) * rng.uniform(0, 3)
         fov = float(rng.choice([1.0, 20.0, 60.0, 120.0]))
-        if clipped and trial % 3 == 1:
-            # the camera a fraction of the box's size away from its surface, looking along it or away from it: corners on
-            # both sides of the camera plane
-            eye = centre + d * float(np.linalg.norm(half)) * rng.uniform(0.9, 1.6)
-            look = eye + np.cross(d, rng.normal(size=3)) + d * rng.uniform(-0.5, 0.5)
-            fov = float(rng.choice([40.0, 60.0, 100.0]))
         cam = po.Camera(po.vec3(*eye), po.vec3(*look), po.vec3(0, 1, 0), fov)
-        rect = emul.screen_rect(tf, bmin, bmax, cam, light, w, h, clipped=clipped)
+        rect = emul.screen_rect(tf, bmin, bmax, cam, light, w, h)
         assert 0 <= rect[0] <= rect[2] <= (w + 7) // 8 and 0 <= rect[1] <= rect[3] <= (h + 7) // 8
         box = po.Aabb(po.vec3(*bmin), po.vec3(*bmax))
         passes = np.zeros((h, w), bool)
@@ -452,11 +442,8 @@ def test_meshes_skipped_by_screen_rectangle_do_not_change_the_frame(po, em_defau
         assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t)) and np.array_equal(got["shadow"], want.shadow), name
 
 
-@pytest.mark.parametrize("clipped", [False, True])
-def test_shadow_rectangle_contains_every_point_whose_shadow_ray_passes_the_root_box(po, clipped):
-    """clipped: instance_shadow_rect (the swept box's hull clipped in front of the camera); every third trial of that run
-    puts the camera inside the scene's bounds, close to the mesh.
-    mesh_shadow_rect promises: a surface point of the scene that is seen outside the rectangle cannot send its shadow ray
+def test_shadow_rectangle_contains_every_point_whose_shadow_ray_passes_the_root_box(po):
+    """mesh_shadow_rect promises: a surface point of the scene that is seen outside the rectangle cannot send its shadow ray
     through the mesh's root box.  Checked with the oracle's transform_ray + ray_aabb_intersect on points spread over the
     scene's bounds (more than the surfaces: the claim holds for every point inside the bounds), for several lights,
     placements and cameras; the point's pixel is its own projection."""
@@ -481,12 +468,8 @@ def test_shadow_rectangle_contains_every_point_whose_shadow_ray_passes_the_root_
         light = po.Light(po.vec3(*np.array(ld, np.float32)), po.vec3(1, 1, 1))
         d = rng.normal(size=3); d /= np.linalg.norm(d)
         eye = pos + d * rng.uniform(15, 40)
-        target = pos + rng.normal(size=3) * 3
-        if clipped and trial % 3 == 1:
-            eye = pos + d * ext * rng.uniform(1.2, 3.0)
-            target = eye + np.cross(d, rng.normal(size=3)) + d * rng.uniform(-0.5, 0.5)
-        cam = po.Camera(po.vec3(*eye), po.vec3(*target), po.vec3(0, 1, 0), float(rng.choice([30.0, 60.0, 100.0])))
-        rect = emul.shadow_rect(tf, bmin, bmax, slo, shi, cam, light, w, h, clipped=clipped)
+        cam = po.Camera(po.vec3(*eye), po.vec3(*(pos + rng.normal(size=3) * 3)), po.vec3(0, 1, 0), float(rng.choice([30.0, 60.0, 100.0])))
+        rect = emul.shadow_rect(tf, bmin, bmax, slo, shi, cam, light, w, h)
         assert 0 <= rect[0] <= rect[2] <= tiles[0] and 0 <= rect[1] <= rect[3] <= tiles[1]
         if (rect[2] - rect[0]) * (rect[3] - rect[1]) < tiles[0] * tiles[1]:
             culled += 1
