@@ -43,6 +43,14 @@ RT_HD F3 unit(F3 a) { return scale(a, rsqrt1(dot(a, a))); }
 RT_HD F3 mul(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }            // vec3.c:39
 RT_HD F3 recip(F3 a) { return f3(rcp1(a.x), rcp1(a.y), rcp1(a.z)); }                // aabb.c:34-38
 
+// scene.c:152-154 stores (unsigned char)fminf(c * 255.0f, 255.0f).  For a negative value (a light colour below zero) C leaves
+// that conversion undefined; the reference as compiled for x86-64 converts to a 32-bit integer by truncation (anything below
+// the integer range gives INT_MIN) and keeps the low byte.  Written out here, so that every compiler gives those bytes: left
+// as the bare cast, device code merged the three byte stores of a pixel on the assumption that each value fits a byte, and a
+// negative red channel spilled into green and blue.
+RT_HD uint8_t byte_of(float v) { return (uint8_t)(uint32_t)(int32_t)fmaxf(v, -2147483648.0f); }
+RT_HD uint8_t colour_byte(float c) { return byte_of(fminf(c * 255.0f, 255.0f)); }
+
 // fminf/fmaxf as the reference's C library evaluates them where the result is stored (box bounds, aabb.c:10-23):
 // of two equal operands -- +0 and -0 -- the second is returned, and a NaN second operand is ignored.
 // Compilers that expand fminf inline pick the other zero.

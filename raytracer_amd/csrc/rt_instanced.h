@@ -166,9 +166,9 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
     float diffuse = 0.2f;
     if (!dark) diffuse = fmaxf(diffuse, dot(n, L));
     color = scale(mul(color, f3(A.light_color)), diffuse);
-    out.r = (uint8_t)(fminf(color.x * 255.0f, 255.0f));
-    out.g = (uint8_t)(fminf(color.y * 255.0f, 255.0f));
-    out.b = (uint8_t)(fminf(color.z * 255.0f, 255.0f));
+    out.r = colour_byte(color.x);
+    out.g = colour_byte(color.y);
+    out.b = colour_byte(color.z);
     out.shadow = dark ? 1 : 0;
     out.dark = dark ? 1 : 0;
     return out;

@@ -364,9 +364,9 @@ __global__ void __launch_bounds__(64) render_instanced_wave(const FrameArgs A, c
                     rgb[0] = rgb[1] = rgb[2] = 50;                                               // scene.c:156
                 } else {
                     const F3 c = scale(L.color, L.dark ? 0.2f : L.lit);                          // scene.c:115,148-149
-                    rgb[0] = (uint8_t)(fminf(c.x * 255.0f, 255.0f));                             // scene.c:152-154 (truncation)
-                    rgb[1] = (uint8_t)(fminf(c.y * 255.0f, 255.0f));
-                    rgb[2] = (uint8_t)(fminf(c.z * 255.0f, 255.0f));
+                    rgb[0] = colour_byte(c.x);                             // scene.c:152-154 (truncation)
+                    rgb[1] = colour_byte(c.y);
+                    rgb[2] = colour_byte(c.z);
                 }
                 if (O.hit_id) O.hit_id[p] = L.who < 0 ? -1 : L.who;
                 if (hit_tri) hit_tri[p] = L.who < 0 ? -1 : (int32_t)L.btri;

@@ -490,9 +490,9 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     const F3 L = f3(A.light_dir);
     if (!dark) diffuse = fmaxf(diffuse, dot(n, L));                    // scene.c:143-144
     color = scale(mul(color, f3(A.light_color)), diffuse);             // scene.c:148-149
-    out.r = (uint8_t)(fminf(color.x * 255.0f, 255.0f));                // scene.c:152-154 (truncation)
-    out.g = (uint8_t)(fminf(color.y * 255.0f, 255.0f));
-    out.b = (uint8_t)(fminf(color.z * 255.0f, 255.0f));
+    out.r = colour_byte(color.x);                // scene.c:152-154 (truncation)
+    out.g = colour_byte(color.y);
+    out.b = colour_byte(color.z);
     out.shadow = dark ? 1 : 0;
     out.dark = dark ? 1 : 0;
     return out;

@@ -116,7 +116,7 @@ RT_HD F3 sample_value(const FrameArgs& A, const SampleArgs& X, const Nodes& node
 // Sum of the sample values in order -> bytes.
 RT_HD void finish_sampled(const SampleArgs& X, F3 acc, SampledOut& out) {
     if (X.spp > 1) { const float n = (float)X.spp; acc = f3(acc.x / n, acc.y / n, acc.z / n); }
-    out.r = (uint8_t)acc.x; out.g = (uint8_t)acc.y; out.b = (uint8_t)acc.z;
+    out.r = byte_of(acc.x); out.g = byte_of(acc.y); out.b = byte_of(acc.z);
 }
 
 template <bool COUNT, class Stack, class Nodes, class Party>

@@ -102,6 +102,21 @@ def scenes(po, seed=0):
         cam = po.Camera(po.vec3(*pos), po.vec3(*center), po.vec3(*b), fov)
         yield f"grazing triangle g={g:.2g} behind a blocker", [rows], [ident], cam, 96, 54
 
+    # attributes the reference never checks: normals of zero length and NaN normals (the shaded normal is 0/0, the shadow ray
+    # starts at a NaN point and meets nothing, fmaxf(0.2f, NaN) keeps the ambient term), texture coordinates far outside
+    # [0, 1), negative, and so large that u - floorf(u) is 0
+    rows = _blob(rng, np.zeros(3), 0.8, 240, size=0.5)
+    for k, r in enumerate(rows):
+        if k % 4 == 0:
+            r[15:24] = 0.0
+        elif k % 4 == 1:
+            r[15:18] = np.nan
+        elif k % 4 == 2:
+            r[9:15] = (-3.25, 17.5, 1.0e9, -1.0e9, 123456.78, -0.001)
+        else:
+            r[9:15] = (1.0e30, -1.0e30, 1.0, 1.0, 0.0, 0.0)
+    yield "zero and NaN normals, texture coordinates far outside the unit square", [rows], [ident], default_cam, 160, 90
+
 
 def build(po, soups, texture):
     """Oracle-side meshes (reference build of every soup)."""
@@ -110,3 +125,48 @@ def build(po, soups, texture):
         t, nodes = po.build_bvh(np.asarray(s, np.float32))
         out.append(po.HostMesh(t, nodes, texture))
     return out
+
+
+def degenerate_views(po):
+    """Yields (name, transforms, camera, light) for the reference driver's three meshes: inputs on which the reference's arithmetic
+    runs into zeros, infinities and NaNs -- a camera looking at its own position or along its up vector (the basis of
+    camera.c:13-15 is 0/0), fields of view of 0, 180 and beyond, a light direction of zero length or straight along an axis,
+    placements far away, with NaN angles or infinite offsets.  The reference reports no errors for any of them (its result is
+    whatever IEEE arithmetic gives, mostly the background); a replacement has to give the same bytes."""
+    nan, inf = float("nan"), float("inf")
+    tf = po.animation_transforms(17)
+    cam = po.default_camera()
+    light = po.default_light()
+
+    def camera(pos=(-3, 3, -3), at=(0, 0, 0), up=(0, 1, 0), fov=60.0):
+        return po.Camera(po.vec3(*pos), po.vec3(*at), po.vec3(*up), fov)
+
+    def raw_light(d, c=(1.4, 1.4, 1.4)):
+        return po.Light(po.vec3(*d), po.vec3(*c))
+
+    def moved(k, pos=None, rot=None):
+        out = list(tf)
+        out[k] = po.Transform(po.vec3(*(pos if pos is not None else tf[k].position.tup())), po.vec3(*(rot if rot is not None else tf[k].rotation.tup())))
+        return out
+
+    yield "camera at its own look-at point", tf, camera(at=(-3, 3, -3)), light
+    yield "camera looking along its up vector", tf, camera(pos=(0, 4, 0), at=(0, 0, 0), up=(0, 1, 0)), light
+    yield "up vector of zero length", tf, camera(up=(0, 0, 0)), light
+    yield "field of view 0", tf, camera(fov=0.0), light
+    yield "field of view 180", tf, camera(fov=180.0), light
+    yield "field of view 270", tf, camera(fov=270.0), light
+    yield "negative field of view", tf, camera(fov=-60.0), light
+    yield "NaN camera position", tf, camera(pos=(nan, 3, -3)), light
+    yield "camera infinitely far away", tf, camera(pos=(-inf, 3, -3)), light
+    yield "light direction of zero length", tf, cam, raw_light((0, 0, 0))
+    yield "light straight down an axis (two zero components)", tf, cam, raw_light((0, 1, 0))
+    yield "light from below", tf, cam, raw_light((0, -1, 0))
+    yield "light direction not normalised", tf, cam, raw_light((3, 4, -2))
+    yield "NaN light direction", tf, cam, raw_light((nan, 1, 0))
+    yield "negative light colour", tf, cam, raw_light(light.direction.tup(), (-1.0, 0.5, 300.0))
+    yield "drone with a NaN angle", moved(0, rot=(0, nan, 0)), cam, light
+    yield "treasure infinitely far away", moved(1, pos=(inf, 0, 0)), cam, light
+    yield "treasure at 1e30", moved(1, pos=(1e30, 0, 0)), cam, light
+    yield "ground with an infinite angle", moved(2, rot=(inf, 0, 0)), cam, light
+    yield "camera inside the treasure's box, axis-parallel view", moved(1, pos=(0, 0, 0), rot=(0, 0, 0)), camera(pos=(0, 0.5, 0), at=(0, 0.5, 5)), light
+    yield "camera exactly on the ground plane, looking along it", tf, camera(pos=(-3, 0, 0), at=(3, 0, 0)), light

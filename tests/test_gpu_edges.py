@@ -400,3 +400,42 @@ def test_culling_keeps_the_reference_result_on_adversarial_scenes_gpu(capi, po):
             assert np.array_equal(out[0].cpu().numpy(), want.rgb) and np.array_equal(out[1].cpu().numpy(), want.rgb), name
         n += 1
     assert n >= 20
+
+
+def test_degenerate_cameras_lights_and_placements_on_the_gpu(capi, po, meshes):
+    """tests/adversarial.py::degenerate_views (zero-length and NaN camera bases, fields of view of 0 / 180 / 270 degrees, zero, NaN
+    and axis-parallel lights, placements with NaN angles or at infinity): rt_render_frame in both traversal modes, rt_render_frames,
+    rt_render_frame_sampled (one sample, one light) and rt_render_frame_instanced against the oracle's reference loop, every
+    plane bit for bit (NaN distances included).  The reference reports no error on any of them (scene.c:52-160 has no checks)."""
+    import torch
+    import adversarial
+    w, h = 96, 54
+    n = 0
+    with capi.Context(0) as c:
+        for m in meshes:
+            c.upload_mesh(m.tris, m.nodes, m.rgba)
+        for name, tfs, cam, l in adversarial.degenerate_views(po):
+            want = po.render_frame(meshes, tfs, cam, l, w, h)
+            ccam = capi.Camera(capi.Vec3(*cam.position.tup()), capi.Vec3(*cam.look_at.tup()), capi.Vec3(*cam.up.tup()), cam.fov)
+            light = capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
+            ctf = conv(capi, tfs)
+            for flags in (0, capi.RT_FLAG_REFERENCE_ORDER):
+                rgb, hid, ht, sh = c.render_host(ccam, light, ctf, w, h, flags=flags)
+                mode = "reference order" if flags else "default"
+                assert np.array_equal(hid, want.hit_id), f"{name}: {(hid != want.hit_id).sum()} hit ids differ ({mode})"
+                assert np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32)), f"{name}: t ({mode})"
+                assert np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb), f"{name}: shading ({mode})"
+            out = torch.zeros((2, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            smp = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+            ins = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+            hi = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+            c.render_frames(ccam, light, [ctf, ctf], w, h, out)
+            c.render_sampled(ccam, [light], ctf, w, h, 1, 0, smp)
+            c.render_instanced(ccam, light, capi.Context.make_instances([0, 1, 2], ctf), w, h, ins, hit_instance=hi)
+            c.sync()
+            assert np.array_equal(out[0].cpu().numpy(), want.rgb) and np.array_equal(out[1].cpu().numpy(), want.rgb), f"{name}: batched frames"
+            assert np.array_equal(smp.cpu().numpy(), want.rgb), f"{name}: sampled frame"
+            assert np.array_equal(ins.cpu().numpy(), want.rgb), f"{name}: instanced frame"
+            assert np.array_equal(hi.cpu().numpy(), np.where(want.hit_id >= 0, want.hit_id >> 24, -1)), f"{name}: instance ids"
+            n += 1
+    assert n >= 20

@@ -590,3 +590,20 @@ def test_second_tree_is_the_same_whether_built_while_packing_or_afterwards(meshe
         soup[:, 17] = 1.0; soup[:, 20] = 1.0; soup[:, 23] = 1.0
         tris, nodes = po.build_bvh(soup)
         assert emul.regroup_routes_agree(tris, nodes) == want, n
+
+
+# ------------------------------------------------------------------------------ zeros, infinities, NaNs
+def test_degenerate_cameras_lights_and_placements_give_the_reference_bytes(po, em_default):
+    """tests/adversarial.py::degenerate_views through the host build of the pixel code (both traversal modes, meshes skipped by
+    screen rectangle as the kernels skip them) against the oracle: every plane, NaN distances included, bit for bit."""
+    import adversarial
+    n = 0
+    for name, tfs, cam, light in adversarial.degenerate_views(po):
+        want = po.render_frame(po.default_meshes(), tfs, cam, light, 96, 54)
+        for kw in ({"full": False}, {"full": True}, {"screen_cull": True}):
+            got = em_default.render(cam, light, tfs, 96, 54, **kw)
+            for k, ref in (("hit_id", want.hit_id), ("shadow", want.shadow), ("rgb", want.rgb)):
+                assert np.array_equal(got[k], ref), f"{name}: {k} differs ({kw})"
+            assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t)), f"{name}: hit_t ({kw})"
+        n += 1
+    assert n >= 20
