@@ -100,6 +100,10 @@ __global__ void k_bounds(const int32_t* seg_of, const int32_t* perm, const Seg* 
         for (int a = 0; a < 3; a++) {
             k[a] = ((unsigned long long)ordered_bits(pick(lo, a)) << 32) | (uint32_t)~(uint32_t)p;       // ties: later position is smaller
             k[3 + a] = ((unsigned long long)ordered_bits(pick(hi, a)) << 32) | (uint32_t)p;              // ties: later position is larger
+            // The reference folds every corner into a box that starts at +-1e30 with fminf / fmaxf (aabb.c:3-23): a NaN never
+            // gets in, nor does anything beyond the starting value.  Such a bound takes no part here either.
+            if (!(pick(lo, a) <= 1e30f)) k[a] = ~0ull;
+            if (!(pick(hi, a) >= -1e30f)) k[3 + a] = 0ull;
         }
     } else {
         for (int a = 0; a < 3; a++) { k[a] = ~0ull; k[3 + a] = 0ull; }
@@ -158,8 +162,9 @@ __global__ void k_node_setup(const Seg* segs, int32_t nseg, const unsigned long 
         }
         const uint32_t pmin = ~(uint32_t)(kmin & 0xFFFFFFFFull);
         const uint32_t pmax = (uint32_t)(kmax & 0xFFFFFFFFull);
-        nd.bmin[a] = pick(box[2 * (size_t)perm[pmin]], a);
-        nd.bmax[a] = pick(box[2 * (size_t)perm[pmax] + 1], a);
+        // no bound took part (all NaN or beyond the starting value): the box keeps what it started with (aabb.c:3-8)
+        nd.bmin[a] = kmin == ~0ull ? 1e30f : pick(box[2 * (size_t)perm[pmin]], a);
+        nd.bmax[a] = kmax == 0ull ? -1e30f : pick(box[2 * (size_t)perm[pmax] + 1], a);
     }
     nd.start = g.start; nd.count = g.count; nd.left = nd.right = -1;
     nodes[g.node] = nd;

@@ -170,3 +170,25 @@ def degenerate_views(po):
     yield "ground with an infinite angle", moved(2, rot=(inf, 0, 0)), cam, light
     yield "camera inside the treasure's box, axis-parallel view", moved(1, pos=(0, 0, 0), rot=(0, 0, 0)), camera(pos=(0, 0.5, 0), at=(0, 0.5, 5)), light
     yield "camera exactly on the ground plane, looking along it", tf, camera(pos=(-3, 0, 0), at=(3, 0, 0)), light
+
+
+def nonfinite_soups(seed=1, sizes=(7, 60, 500, 5000)):
+    """Yields (name, soup [n,24] f32): triangles with NaN and infinite vertices, coordinates whose sums overflow, denormals, all
+    triangles identical, flat sets.  The reference checks nothing (mesh.c:40-76 reads whatever sscanf gives): its box folding
+    ignores NaNs and whatever lies beyond +-1e30 (aabb.c:3-23), a NaN centroid makes every comparison of the partition false
+    (bvh.c:36-49), and the walk's slab and triangle tests reject NaNs; builders and kernels have to end up with the same bits."""
+    rng = np.random.default_rng(seed)
+    for n in sizes:
+        base = rng.normal(size=(n, 24)).astype(np.float32) * np.float32(0.7)
+        s = base.copy(); s[rng.integers(n), 0] = np.nan; yield f"one NaN coordinate, n={n}", s
+        s = base.copy(); s[::3, :9] = np.nan; yield f"every third triangle NaN, n={n}", s
+        s = base.copy(); s[n // 2:, :9] = np.nan; yield f"second half NaN, n={n}", s
+        s = base.copy(); s[:, :9] = np.nan; yield f"all NaN, n={n}", s
+        s = base.copy(); s[rng.integers(n), 4] = np.inf; yield f"one infinite coordinate, n={n}", s
+        s = base.copy(); s[::2, 1] = -np.inf; s[1::4, 1] = np.inf; yield f"infinities of both signs, n={n}", s
+        s = base.copy(); s[:, 0] = s[:, 3] = s[:, 6] = np.inf; yield f"all x infinite, n={n}", s
+        with np.errstate(over="ignore"):
+            s = base.copy(); s[:, :9] *= np.float32(3e38); yield f"sums that overflow, n={n}", s
+        s = base.copy(); s[:, :9] *= np.float32(1e-42); yield f"denormals, n={n}", s
+        s = base.copy(); s[:, :9] = s[0, :9]; yield f"all triangles identical, n={n}", s
+        s = base.copy(); s[:, 0] = s[:, 3] = s[:, 6] = np.float32(1.0); yield f"flat in x, n={n}", s

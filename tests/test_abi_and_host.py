@@ -197,6 +197,23 @@ def test_rt_bvh_build_keeps_the_reference_sign_of_zero_bounds(capi, po):
         R.close()
 
 
+def test_rt_bvh_build_on_nan_infinite_and_overflowing_vertices(capi, po):
+    """tests/adversarial.py::nonfinite_soups: rt_bvh_build against the oracle's build and, where it is present, the compiled
+    reference's create_bvh -- triangle order and node array bit for bit."""
+    import adversarial
+    n = 0
+    for name, soup in adversarial.nonfinite_soups(sizes=(7, 60, 500)):
+        post, nodes = capi.build_bvh(soup)
+        want_t, want_n = po.build_bvh(soup)
+        assert np.array_equal(bits(post), bits(want_t)) and nodes.tobytes() == want_n.tobytes(), name
+        if po.ref_available():
+            R = po.RefScene([soup], [np.zeros((2, 2, 4), np.uint8)])
+            assert R.nodes(0).tobytes() == nodes.tobytes() and np.array_equal(bits(R.triangles(0)), bits(post)), name
+            R.close()
+        n += 1
+    assert n >= 30
+
+
 def test_rt_bvh_build_argument_errors(capi):
     L = capi.lib()
     used = C.c_int32(0)

@@ -94,6 +94,42 @@ def test_device_build_failed_partitions_and_signed_zeros(capi, ctx):
     same(capi, ctx, signed_zero_soup(5000, 6))
 
 
+def test_device_build_on_nan_infinite_and_overflowing_vertices(capi, ctx):
+    """tests/adversarial.py::nonfinite_soups: bounds that are NaN or lie beyond the +-1e30 an empty box starts with take no part
+    in a node's box (aabb.c:3-23), a NaN centroid fails every comparison of the partition -- same bits as the host build."""
+    import adversarial
+    n = 0
+    for name, soup in adversarial.nonfinite_soups():
+        same(capi, ctx, soup)
+        n += 1
+    assert n >= 40
+
+
+def test_upload_soup_of_nan_and_infinite_vertices_renders_like_the_reference(capi, po):
+    """The same soups through rt_mesh_upload_soup with build and packing on the device (device_build_min = 1): post-build
+    triangle order equal to the oracle's build, frames equal to the oracle's reference loop over that build."""
+    import adversarial
+    tex = np.full((4, 4, 4), 180, np.uint8)
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    pl = po.default_light()
+    light = capi.Light(capi.Vec3(*pl.direction.tup()), capi.Vec3(*pl.color.tup()))
+    ident = [po.Transform(po.vec3(0, 0, 0), po.vec3(0.2, 0.4, 0.1))]
+    ctf = [capi.Transform(capi.Vec3(0, 0, 0), capi.Vec3(0.2, 0.4, 0.1))]
+    n = 0
+    for name, soup in adversarial.nonfinite_soups(sizes=(60, 500)):
+        want_t, want_n = po.build_bvh(soup)
+        want = po.render_frame([po.HostMesh(want_t, want_n, tex)], ident, po.default_camera(), pl, 96, 54)
+        with capi.Context(0) as c:
+            c.set_option("device_build_min", 1)
+            mid, post = c.upload_soup(soup, tex, want_triangles=True)
+            assert np.array_equal(post.view(np.uint32), want_t.view(np.uint32)), name
+            rgb, hid, ht, sh = c.render_host(cam, light, ctf, 96, 54)
+            assert np.array_equal(hid, want.hit_id) and np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32)), name
+            assert np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb), name
+        n += 1
+    assert n >= 20
+
+
 def test_device_build_empty_and_argument_errors(capi, ctx):
     import ctypes as C
     L = capi.lib()

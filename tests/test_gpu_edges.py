@@ -439,3 +439,26 @@ def test_degenerate_cameras_lights_and_placements_on_the_gpu(capi, po, meshes):
             assert np.array_equal(hi.cpu().numpy(), np.where(want.hit_id >= 0, want.hit_id >> 24, -1)), f"{name}: instance ids"
             n += 1
     assert n >= 20
+
+
+def test_meshes_with_nan_and_infinite_vertices_render_like_the_reference(capi, po):
+    """tests/adversarial.py::nonfinite_soups as meshes (boxes with NaN and infinite bounds, triangles the Moeller-Trumbore test can
+    only reject): both traversal modes against the oracle's reference loop, every plane."""
+    import adversarial
+    tex = checker()
+    cam, light = camera_light(capi, po)
+    ident = [po.Transform(po.vec3(0, 0, 0), po.vec3(0.2, 0.4, 0.1))]
+    n = hits = 0
+    for name, soup in adversarial.nonfinite_soups(sizes=(7, 60, 500)):
+        t, nodes = capi.build_bvh(soup)
+        want = po.render_frame([po.HostMesh(t, nodes, tex)], ident, po.default_camera(), po.default_light(), 96, 54)
+        with capi.Context(0) as c:
+            c.upload_mesh(t, nodes, tex)
+            for flags in (0, capi.RT_FLAG_REFERENCE_ORDER):
+                rgb, hid, ht, sh = c.render_host(cam, light, conv(capi, ident), 96, 54, flags=flags)
+                assert np.array_equal(hid, want.hit_id), f"{name}: hit ids (flags {flags})"
+                assert np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32)), f"{name}: t (flags {flags})"
+                assert np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb), f"{name}: shading (flags {flags})"
+        hits += int((want.hit_id >= 0).sum())
+        n += 1
+    assert n >= 30 and hits > 5000

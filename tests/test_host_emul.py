@@ -607,3 +607,27 @@ def test_degenerate_cameras_lights_and_placements_give_the_reference_bytes(po, e
             assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t)), f"{name}: hit_t ({kw})"
         n += 1
     assert n >= 20
+
+
+def test_meshes_with_nan_and_infinite_vertices_through_the_host_build_of_the_pixel_code(po):
+    """tests/adversarial.py::nonfinite_soups as meshes: packer (both trees) and traversal (both modes) on boxes with NaN and
+    infinite bounds against the oracle's reference loop, every plane."""
+    import adversarial
+    tex = checker()
+    ident = [po.Transform(po.vec3(0, 0, 0), po.vec3(0.2, 0.4, 0.1))]
+    cam, light = po.default_camera(), po.default_light()
+    n = 0
+    for name, soup in adversarial.nonfinite_soups(sizes=(7, 60, 500)):
+        t, nodes = po.build_bvh(soup)
+        want = po.render_frame([po.HostMesh(t, nodes, tex)], ident, cam, light, 96, 54)
+        for regroup in (False, True):
+            s = emul.Scene(regroup=regroup)
+            assert s.add(t, nodes, tex) == 0, (name, s.error())
+            for full in (False, True):
+                got = s.render(cam, light, ident, 96, 54, full=full)
+                for k, ref in (("hit_id", want.hit_id), ("shadow", want.shadow), ("rgb", want.rgb)):
+                    assert np.array_equal(got[k], ref), f"{name}: {k} differs (regroup {regroup}, reference order {full})"
+                assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t)), name
+            s.close()
+        n += 1
+    assert n >= 30
