@@ -75,6 +75,22 @@ def test_product_pixel_code_equals_restatement(po, meshes, em_default, spp, n_li
     assert want.counters["shadow_rays"] == want.counters["hit_pixels"] * n_lights
 
 
+def test_product_pixel_code_on_degenerate_views_and_lights(po, meshes, em_default):
+    """tests/adversarial.py::degenerate_views with three samples and a second light whose colour has a negative and a huge
+    component: the host build of the product's pixel code against the restatement (unpinned by the reference beyond one sample
+    and one light; the byte written for a negative mean follows the reference's x86 conversion in both)."""
+    import adversarial
+    odd = po.Light(po.vec3(0.0, -1.0, 0.0), po.vec3(-2.0, 0.25, 1.0e9))
+    n = 0
+    for name, tfs, cam, light in adversarial.degenerate_views(po):
+        want = po.render_frame_sampled(meshes, tfs, cam, [light, odd], 3, 7, 64, 36)
+        got = em_default.render_sampled(cam, [light, odd], tfs, 3, 7, 64, 36)
+        assert np.array_equal(got["rgb"], want.rgb), name
+        assert np.array_equal(got["hit_id"], want.hit_id), name
+        n += 1
+    assert n >= 20
+
+
 def test_more_samples_smooth_edges_and_seed_matters(po, meshes):
     tfs = po.animation_transforms(0)
     cam, ls = po.default_camera(), [po.default_light()]
@@ -171,3 +187,33 @@ def test_gpu_sampled_argument_errors(gscene, po):
         with pytest.raises(capi.RtError):
             gscene.render_sampled(cam, kwargs.get("lights", l), kwargs.get("tfs", t), 8, 8, kwargs.get("spp", 2), 0, rgb,
                                   flags=kwargs.get("flags", 0))
+
+
+@pytest.mark.gpu
+def test_gpu_sampled_on_degenerate_views_and_lights(gscene, po, meshes):
+    """tests/adversarial.py::degenerate_views with several samples and a second, odd light (negative and huge colour components:
+    the sample values then run below zero, and the byte written follows the reference's x86 conversion): looped and split
+    kernels against the CPU restatement.  Parity beyond one sample and one light is unpinned by the reference; this pins
+    the kernels to the restatement where the arithmetic leaves the ordinary."""
+    import torch
+    import adversarial
+    from raytracer_amd import capi
+    w, h = 64, 36
+    odd = po.Light(po.vec3(0.0, -1.0, 0.0), po.vec3(-2.0, 0.25, 1.0e9))
+    n = 0
+    rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    for name, tfs, cam, light in adversarial.degenerate_views(po):
+        ls = [light, odd]
+        want = po.render_frame_sampled(meshes, tfs, cam, ls, 3, 7, w, h)
+        ccam = capi.Camera(capi.Vec3(*cam.position.tup()), capi.Vec3(*cam.look_at.tup()), capi.Vec3(*cam.up.tup()), cam.fov)
+        _, t, l = to_capi(capi, po, tfs, ls)
+        for split in (1, 0):
+            gscene.set_option("sampled_split", split)
+            rgb.zero_()
+            torch.cuda.synchronize()
+            gscene.render_sampled(ccam, l, t, w, h, 3, 7, rgb)
+            gscene.sync()
+            assert np.array_equal(rgb.cpu().numpy(), want.rgb), (name, split, int((rgb.cpu().numpy() != want.rgb).any(axis=-1).sum()))
+        n += 1
+    gscene.set_option("sampled_split", 1)
+    assert n >= 20
