@@ -202,6 +202,35 @@ def test_kept_hierarchy_stays_a_valid_tree_under_random_changes(tmp_path):
         assert info["errors"] == 0 and info["reused"] > 200
 
 
+def nonfinite_lists(po):
+    """Yields (name, mesh ids, transforms): a 6 x 6 grid scene in which a tenth, half or all of the 38 list entries have NaN or
+    infinite angles or positions.  The reference's loop just finds no hit in such an entry (its ray transform yields NaNs); the
+    hierarchy over the world boxes has to cope with boxes that are NaN or infinite and still propose every other entry."""
+    nan, inf = float("nan"), float("inf")
+    rng = np.random.default_rng(4)
+    kinds = (("NaN angles", lambda t: po.Transform(t.position, po.vec3(0, nan, 0))),
+             ("NaN positions", lambda t: po.Transform(po.vec3(nan, 0, 0), t.rotation)),
+             ("infinite positions", lambda t: po.Transform(po.vec3(inf, 0.5, -inf), t.rotation)),
+             ("positions of 1e30", lambda t: po.Transform(po.vec3(1e30, 0.5, 1e30), t.rotation)),
+             ("infinite angles", lambda t: po.Transform(t.position, po.vec3(inf, 0, 0))))
+    for label, bad in kinds:
+        for frac in (0.1, 0.5, 1.0):
+            ids, tfs = grid_scene(po, 6, seed=3)
+            for k in range(len(tfs)):
+                if rng.uniform() < frac:
+                    tfs[k] = bad(tfs[k])
+            yield f"{label} on {frac:.0%} of the entries", ids, tfs
+
+
+def test_entries_with_nan_and_infinite_placements(po, meshes, em_default):
+    n = 0
+    for name, ids, tfs in nonfinite_lists(po):
+        fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), 96, 54)
+        check(em_default.render_instanced(po.default_camera(), po.default_light(), ids, tfs, 96, 54), fr, inst, tri)
+        n += 1
+    assert n == 15
+
+
 def test_no_instances_is_background(po, em_default):
     got = em_default.render_instanced(po.default_camera(), po.default_light(), [], [], 16, 9)
     assert (got["rgb"] == 50).all() and (got["hit_inst"] == -1).all() and (got["shadow"] == 255).all()
@@ -406,3 +435,11 @@ def test_gpu_wave_scheduled_kernel_equals_reference_loop(gscene, po, meshes, til
         assert 0 in inst and 2 not in inst and 4 not in inst
     finally:
         gscene.set_option("instanced_wave", 0)
+
+
+@pytest.mark.gpu
+def test_gpu_entries_with_nan_and_infinite_placements(gscene, po, meshes):
+    """nonfinite_lists on the GPU, one call after the other on one context (kept hierarchy, kept placement constants)."""
+    for name, ids, tfs in nonfinite_lists(po):
+        fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), 96, 54)
+        check(gpu_render(gscene, po, ids, tfs, 96, 54), fr, inst, tri)
