@@ -462,3 +462,44 @@ def test_meshes_with_nan_and_infinite_vertices_render_like_the_reference(capi, p
         hits += int((want.hit_id >= 0).sum())
         n += 1
     assert n >= 30 and hits > 5000
+
+
+def test_odd_texture_shapes_and_extreme_frame_shapes(capi, po, meshes):
+    """Textures of 1 x 1, one row, one column and very oblong shapes with texture coordinates outside [0, 1) (mesh.c:138-149
+    multiplies by size - 1, which is 0 for a size of 1); frames one pixel wide or high, 16384 x 1, 3 x 2051, sizes one above and
+    below a tile -- rt_render_frame (all planes), rt_render_frames, rt_render_frame_sampled and rt_render_frame_instanced."""
+    import torch
+    import adversarial
+    rng = np.random.default_rng(2)
+    cam, light = camera_light(capi, po)
+    rows = np.asarray(adversarial._blob(rng, np.zeros(3), 0.9, 300, size=0.6), np.float32)
+    rows[:, 9:15] = rng.uniform(-2, 3, size=(300, 6)).astype(np.float32)
+    t, nodes = capi.build_bvh(rows)
+    ident = [po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))]
+    for shape in ((1, 1), (1, 7), (5, 1), (2, 2), (3, 1000), (1000, 3)):
+        tex = rng.integers(0, 256, size=shape + (4,), dtype=np.uint8)
+        want = po.render_frame([po.HostMesh(t, nodes, tex)], ident, po.default_camera(), po.default_light(), 96, 54)
+        with capi.Context(0) as c:
+            c.upload_mesh(t, nodes, tex)
+            rgb, hid, _, _ = c.render_host(cam, light, conv(capi, ident), 96, 54)
+        assert np.array_equal(rgb, want.rgb) and np.array_equal(hid, want.hit_id), f"texture of shape {shape}"
+    tfs = po.animation_transforms(33)
+    ctf = conv(capi, tfs)
+    with capi.Context(0) as c:
+        for m in meshes:
+            c.upload_mesh(m.tris, m.nodes, m.rgba)
+        for w, h in ((1, 97), (97, 1), (8, 8), (9, 9), (7, 7), (4099, 3), (3, 2051), (65, 63), (16384, 1)):
+            want = po.render_frame(meshes, tfs, po.default_camera(), po.default_light(), w, h)
+            rgb, hid, ht, sh = c.render_host(cam, light, ctf, w, h)
+            assert np.array_equal(rgb, want.rgb) and np.array_equal(hid, want.hit_id) and np.array_equal(sh, want.shadow), (w, h)
+            assert np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32)), (w, h)
+            three = torch.zeros((3, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            smp = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+            ins = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            c.render_frames(cam, light, [ctf, ctf, ctf], w, h, three)
+            c.render_sampled(cam, [light], ctf, w, h, 1, 0, smp)
+            c.render_instanced(cam, light, capi.Context.make_instances([0, 1, 2], ctf), w, h, ins)
+            c.sync()
+            assert all(np.array_equal(three[k].cpu().numpy(), want.rgb) for k in range(3)), (w, h)
+            assert np.array_equal(smp.cpu().numpy(), want.rgb) and np.array_equal(ins.cpu().numpy(), want.rgb), (w, h)
