@@ -425,6 +425,12 @@ def test_degenerate_cameras_lights_and_placements_on_the_gpu(capi, po, meshes):
                 assert np.array_equal(hid, want.hit_id), f"{name}: {(hid != want.hit_id).sum()} hit ids differ ({mode})"
                 assert np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32)), f"{name}: t ({mode})"
                 assert np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb), f"{name}: shading ({mode})"
+            for variant in range(c.get_option("n_variants")):   # persistent, cooperative, two-pass and lean kernels as well
+                c.set_option("variant", variant)
+                rgb, hid, ht, sh = c.render_host(ccam, light, ctf, w, h)
+                assert np.array_equal(hid, want.hit_id) and np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32)), f"{name}: variant {variant}"
+                assert np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb), f"{name}: variant {variant}"
+            c.set_option("variant", c.get_option("default_variant"))
             out = torch.zeros((2, h, w, 3), dtype=torch.uint8, device="cuda:0")
             smp = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
             ins = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
