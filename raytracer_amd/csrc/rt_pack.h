@@ -601,9 +601,23 @@ inline bool coop_rect(const WorldBox& b, const double scene_lo[3], const double 
 
 // Rectangle of tiles around the projections of `n` world points, each allowed to be off by `slack` in space; false (rect =
 // whole frame) when a point is at or behind the camera plane or the allowance exceeds what the projection can tell.
+// The camera basis as camera.c:13-15 leaves it is orthonormal up to rounding -- unless its inputs are degenerate: an up vector
+// of 1e30 overflows the normalisation and leaves right = up = 0 (every pixel then has the same ray), one of 1e-20 takes it
+// into denormals and leaves vectors that are not of unit length; nothing can be told from a projection then.  True when pixels and directions correspond as the projections below assume.
+inline bool camera_basis_is_orthonormal(const FrameArgs& A) {
+    const float* v[3] = {A.cam_right, A.cam_up, A.cam_fwd};
+    for (int i = 0; i < 3; i++)
+        for (int j = i; j < 3; j++) {
+            const double d = (double)v[i][0] * v[j][0] + (double)v[i][1] * v[j][1] + (double)v[i][2] * v[j][2];
+            if (!(fabs(d - (i == j ? 1.0 : 0.0)) < 4e-6)) return false;           // also false for NaN; float normalisation leaves 2e-7
+        }
+    return true;
+}
+
 inline bool tiles_around(const double (*pts)[3], int n, double slack, const FrameArgs& A, int32_t rect[4]) {
     const int tiles_x = (A.width + 7) / 8, tiles_y = (A.full_height + 7) / 8;
     rect[0] = 0; rect[1] = 0; rect[2] = tiles_x; rect[3] = tiles_y;
+    if (!camera_basis_is_orthonormal(A)) return false;
     double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300}, z_min = 1e300, s_max = 0.0;
     for (int c = 0; c < n; c++) {
         double w[3];

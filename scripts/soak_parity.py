@@ -30,21 +30,29 @@ def instanced(a):
     sizes = [(160, 90), (97, 61), (200, 40)]
     pixels = hits = 0
     dev = "cuda:0"
+    special = [0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e30, -1e30, 1e-30, 1e-42, 1e-7, -1e-7, 1.0, 90.0, 180.0, 360.0]
+
+    def wild(values):
+        return tuple(float(rng.choice(special)) if rng.uniform() < a.wild else float(v) for v in values)
+
     for k in range(a.scenes):
         n = int(rng.integers(1, 41))
         spread = float(rng.choice([1.0, 3.0, 8.0]))
         ids = [int(rng.choice([0, 1, 1, 1, 2])) for _ in range(n)]
-        tfs = [po.Transform(po.vec3(*rng.uniform(-spread, spread, 3)), po.vec3(*rng.uniform(-3.2, 3.2, 3))) for _ in range(n)]
+        tfs = [po.Transform(po.vec3(*wild(rng.uniform(-spread, spread, 3))), po.vec3(*wild(rng.uniform(-3.2, 3.2, 3)))) for _ in range(n)]
         if n > 3 and rng.uniform() < 0.3:                       # coincident entries: the earlier one wins
             tfs[n - 1] = tfs[0]; ids[n - 1] = ids[0]
         eye = rng.uniform(-1.2 * spread - 2, 1.2 * spread + 2, 3)
         at = rng.uniform(-spread, spread, 3)
         if np.linalg.norm(eye - at) < 1e-3:
             at = eye + np.array([0.3, -0.2, 0.9])
-        fov = float(rng.uniform(20, 110))
-        ocam = po.Camera(po.vec3(*eye), po.vec3(*at), po.vec3(0, 1, 0), fov)
-        olight = po.lib().orc_make_light(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(0.3, 1.6, 3)))
-        cam = capi.Camera(capi.Vec3(*ocam.position.tup()), capi.Vec3(*ocam.look_at.tup()), capi.Vec3(0, 1, 0), fov)
+        fov = wild([rng.uniform(20, 110)])[0]
+        ocam = po.Camera(po.vec3(*wild(eye)), po.vec3(*wild(at)), po.vec3(*wild((0, 1, 0))), fov)
+        if a.wild > 0 and rng.uniform() < 0.5:
+            olight = po.Light(po.vec3(*wild(rng.normal(size=3))), po.vec3(*wild(rng.uniform(-0.5, 2.0, 3))))
+        else:
+            olight = po.lib().orc_make_light(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(0.3, 1.6, 3)))
+        cam = capi.Camera(capi.Vec3(*ocam.position.tup()), capi.Vec3(*ocam.look_at.tup()), capi.Vec3(*ocam.up.tup()), fov)
         light = capi.Light(capi.Vec3(*olight.direction.tup()), capi.Vec3(*olight.color.tup()))
         w, h = sizes[k % len(sizes)]
         fr, inst, tri = po.render_frame_ids([meshes[i] for i in ids], tfs, ocam, olight, w, h)
@@ -60,14 +68,17 @@ def instanced(a):
                 and np.array_equal(t.cpu().numpy().view(np.uint32), fr.hit_t.view(np.uint32))
                 and np.array_equal(sh.cpu().numpy(), fr.shadow) and np.array_equal(rgb.cpu().numpy(), fr.rgb))
         if not same:
-            print(json.dumps({"scene": k, "seed": a.seed, "instances": n, "size": [w, h], "differs": True}))
+            print(json.dumps({"scene": k, "seed": a.seed, "instances": n, "size": [w, h], "differs": True, "ids": ids,
+                              "placements": [[repr(v) for v in t.position.tup() + t.rotation.tup()] for t in tfs],
+                              "camera": [repr(v) for v in ocam.position.tup() + ocam.look_at.tup() + ocam.up.tup()] + [repr(fov)],
+                              "light": [repr(v) for v in olight.direction.tup() + olight.color.tup()]}))
             sys.exit(1)
         pixels += w * h
         hits += int((inst >= 0).sum())
         if (k + 1) % 100 == 0:
             print(f"[soak] {k + 1} instanced scenes identical", file=sys.stderr, flush=True)
     print(json.dumps({"scenes": a.scenes, "seed": a.seed, "path": "rt_render_frame_instanced, lists of 1..40 placed meshes", "pixels": pixels,
-                      "pixels_with_a_hit": hits, "planes": "rgb, instance, triangle, closest t (bits), shadow", "identical": True}))
+                      "pixels_with_a_hit": hits, "planes": "rgb, instance, triangle, closest t (bits), shadow", "identical": True, "wild": a.wild}))
     ctx.close()
 
 
@@ -75,6 +86,9 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--scenes", type=int, default=500)
     p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--wild", type=float, default=0.0,
+                   help="probability with which each scalar of a scene (placements, camera, field of view, light) is replaced by a special "
+                        "value: zeros of either sign, infinities, NaN, 1e30, 1e-30, a denormal, 1e-7, 90/180/360 for angles")
     p.add_argument("--instanced", action="store_true",
                    help="lists of 1..40 placed meshes through rt_render_frame_instanced against the reference's loop over the list")
     a = p.parse_args()
@@ -91,21 +105,30 @@ def main():
     rng = np.random.default_rng(a.seed)
     sizes = [(160, 90), (200, 120), (97, 61), (33, 130), (256, 8)]
     pixels = hits = 0
+    special = [0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e30, -1e30, 1e-30, 1e-42, 1e-7, -1e-7, 1.0, 90.0, 180.0, 360.0]
+
+    def wild(values):
+        """Each value replaced by a special one with probability --wild."""
+        return tuple(float(rng.choice(special)) if rng.uniform() < a.wild else float(v) for v in values)
+
     for k in range(a.scenes):
         spread = float(rng.choice([0.5, 1.5, 5.0, 50.0]))
         tfs = []
         for m in range(3):
             pos = rng.uniform(-spread, spread, 3)
             rot = rng.uniform(-3.2, 3.2, 3) if (m < 2 or rng.uniform() < 0.3) else rng.uniform(-0.05, 0.05, 3)
-            tfs.append(po.Transform(po.vec3(*pos), po.vec3(*rot)))
+            tfs.append(po.Transform(po.vec3(*wild(pos)), po.vec3(*wild(rot))))
         eye = rng.uniform(-1.2 * spread - 2, 1.2 * spread + 2, 3)
         at = rng.uniform(-spread, spread, 3)
         if np.linalg.norm(eye - at) < 1e-3:
             at = eye + np.array([0.3, -0.2, 0.9])
-        fov = float(rng.uniform(15, 120))
+        fov = wild([rng.uniform(15, 120)])[0]
         up = (0, 1, 0) if rng.uniform() < 0.8 else tuple(rng.normal(size=3))
-        ocam = po.Camera(po.vec3(*eye), po.vec3(*at), po.vec3(*up), fov)
-        olight = po.lib().orc_make_light(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(0.3, 1.6, 3)))
+        ocam = po.Camera(po.vec3(*wild(eye)), po.vec3(*wild(at)), po.vec3(*wild(up)), fov)
+        if a.wild > 0 and rng.uniform() < 0.5:       # the light as a caller may fill it in: not normalised, any colour
+            olight = po.Light(po.vec3(*wild(rng.normal(size=3))), po.vec3(*wild(rng.uniform(-0.5, 2.0, 3))))
+        else:
+            olight = po.lib().orc_make_light(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(0.3, 1.6, 3)))
         cam = capi.Camera(capi.Vec3(*ocam.position.tup()), capi.Vec3(*ocam.look_at.tup()), capi.Vec3(*ocam.up.tup()), fov)
         light = capi.Light(capi.Vec3(*olight.direction.tup()), capi.Vec3(*olight.color.tup()))
         w, h = sizes[k % len(sizes)]
@@ -117,14 +140,21 @@ def main():
         if not same:
             print(json.dumps({"scene": k, "seed": a.seed, "size": [w, h], "ids_differ": int((hid != want.hit_id).sum()),
                               "t_differ": int((ht.view(np.uint32) != want.hit_t.view(np.uint32)).sum()),
-                              "shadow_differ": int((sh != want.shadow).sum()), "rgb_differ": int((rgb != want.rgb).any(-1).sum())}))
+                              "shadow_differ": int((sh != want.shadow).sum()), "rgb_differ": int((rgb != want.rgb).any(-1).sum()),
+                              "placements": [[repr(v) for v in t.position.tup() + t.rotation.tup()] for t in tfs],
+                              "camera": [repr(v) for v in ocam.position.tup() + ocam.look_at.tup() + ocam.up.tup()] + [repr(fov)],
+                              "light": [repr(v) for v in olight.direction.tup() + olight.color.tup()]}))
             sys.exit(1)
         pixels += w * h
         hits += int((want.hit_id >= 0).sum())
         if (k + 1) % 100 == 0:
             print(f"[soak] {k + 1} scenes identical", file=sys.stderr, flush=True)
-    print(json.dumps({"scenes": a.scenes, "seed": a.seed, "pixels": pixels, "pixels_with_a_hit": hits,
-                      "planes": "rgb, hit id, closest t (bits), shadow", "identical": True}))
+    out = {"scenes": a.scenes, "seed": a.seed, "pixels": pixels, "pixels_with_a_hit": hits,
+           "planes": "rgb, hit id, closest t (bits), shadow", "identical": True}
+    if a.wild > 0:
+        out["wild"] = a.wild
+        out["special_values"] = "each scalar of placements, camera, field of view and light replaced with that probability by one of " + repr(special)
+    print(json.dumps(out))
     ctx.close()
 
 

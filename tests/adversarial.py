@@ -152,6 +152,11 @@ def degenerate_views(po):
     yield "camera at its own look-at point", tf, camera(at=(-3, 3, -3)), light
     yield "camera looking along its up vector", tf, camera(pos=(0, 4, 0), at=(0, 0, 0), up=(0, 1, 0)), light
     yield "up vector of zero length", tf, camera(up=(0, 0, 0)), light
+    yield "up vector of 1e30 (the normalisation overflows: right = up = 0, every pixel gets the forward ray)", tf, camera(up=(0, 1, 1e30)), light
+    yield "up vector of 1e-20 (the normalisation runs into denormals)", tf, camera(up=(0, 1e-20, 0)), light
+    yield "up vector of 1e-30", tf, camera(up=(0, 1e-30, 0)), light
+    yield "look-at point 1e-20 away from the camera", tf, camera(pos=(0, 1, -2), at=(1e-20, 1, -2 + 1e-20)), light
+    yield "camera 1e19 away", tf, camera(pos=(-3e19, 3e19, -3e19)), light
     yield "field of view 0", tf, camera(fov=0.0), light
     yield "field of view 180", tf, camera(fov=180.0), light
     yield "field of view 270", tf, camera(fov=270.0), light
