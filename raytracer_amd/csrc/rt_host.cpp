@@ -130,6 +130,7 @@ struct rt_ctx {
     std::vector<InstanceCache> inst_cache;
     StandingTlas standing;         // rt_render_frame_instanced: the hierarchy over the instances, kept between calls
     int keep_hierarchy = 1;
+    float box_allowance = 0.0f;    // what the instances' world boxes were widened by last time (scene_box_allowance)
     int screen_cull = 1;           // meshes are skipped for camera rays of tiles their root box cannot reach (mesh_screen_rect)
     int fast = 0;                  // 1: rt_render_frame / rt_render_frames / strips run the fast build of the kernels (not bit-exact)
     int instanced_wave = 0;        // rt_render_frame_instanced: 0 = one lane per pixel, nested loops (faster); 1..8 = the per-wavefront scheduler, that many tiles per wave
@@ -1005,6 +1006,8 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
         }
         if (!inst[i].empty) { boxes.push_back(c.box); ids.push_back((uint32_t)i); }
     }
+    ctx->box_allowance = settled_allowance(ctx->box_allowance, scene_box_allowance(boxes, A.cam_pos));
+    widen_boxes(boxes, ctx->box_allowance);
     Tlas T;
     if (ctx->keep_hierarchy) (void)ctx->standing.update(boxes, ids, (size_t)n_instances, T);
     else TlasBuilder(boxes, ids, T).run();

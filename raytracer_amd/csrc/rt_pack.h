@@ -171,7 +171,7 @@ public:
         out_.root_ref = ref;
         out_.ref_root = ref;
         out_.tree_pairs = (uint32_t)out_.pairs.size();
-        out_.empty = false;
+        out_.empty = n_tris_ == 0;                               // a tree over no triangles (one node, bvh.c:8-18) never yields a hit either
         if (out_.depth + 2 > kStackDepth || out_.depth > RT_MAX_TREE_DEPTH) { err = "BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
         if (regroup_ && leaves_ok_ && leaves_.size() >= 4 && leaves_.size() <= ((size_t)1 << 23)) regroup();
         if (regroup_) build_grid();
@@ -717,6 +717,38 @@ inline InstanceBox instance_box(const rt_transform& tf, const float* bmin, const
         b.hi[i] = nextafterf((float)(w.hi[i] + pad), INFINITY);
     }
     return b;
+}
+
+// What the padding above leaves out: the exact test in an instance's own space works on the ray's origin moved into that
+// space, whose rounding error goes with the magnitudes involved -- the instance's position, but also the origin itself: the
+// camera, or, for a shadow ray, a surface point anywhere in the scene.  With an entry placed at 1e30 (the reference accepts any
+// placement) those errors are of the order of 1e23, the exact test then accepts or rejects by rounding alone, and rays that start
+// on that entry do the same against every other one.  So every box is widened once more, on all sides, by 2^-18 of the
+// largest finite coordinate magnitude of the scene and the camera (64 units in the last place, the allowance of
+// mesh_screen_rect), rounded up to a power of two so that it changes rarely and a kept hierarchy stays valid from frame to
+// frame.  An ordinary scene (coordinates of tens) gets 5e-4.
+inline float scene_box_allowance(const std::vector<InstanceBox>& boxes, const float* cam_pos) {
+    double mag = 0.0;
+    auto take = [&](float v) { const double a = fabs((double)v); if (a <= 3.0e38 && a > mag) mag = a; };       // false for NaN and infinity
+    for (int i = 0; i < 3; i++) take(cam_pos[i]);
+    for (const InstanceBox& b : boxes)
+        for (int i = 0; i < 3; i++) { take(b.lo[i]); take(b.hi[i]); }
+    if (!(mag > 0.0)) return 0.0f;
+    int e = 0;
+    (void)frexp(mag, &e);                                      // mag < 2^e
+    return (float)ldexp(1.0, e - 18);                          // overflows to infinity only beyond 2^127 * 2^18: never
+}
+// The allowance to use given the one used last time (0 at first): kept while it is at least what the scene needs now and at
+// most four times that, so that entries moving about a scene do not change every box each time the largest coordinate
+// crosses a power of two.
+inline float settled_allowance(float kept, float need) { return (kept >= need && kept <= 4.0f * need) ? kept : need; }
+inline void widen_boxes(std::vector<InstanceBox>& boxes, float by) {
+    if (!(by > 0.0f)) return;
+    for (InstanceBox& b : boxes)
+        for (int i = 0; i < 3; i++) {
+            b.lo[i] = nextafterf(b.lo[i] - by, -INFINITY);
+            b.hi[i] = nextafterf(b.hi[i] + by, INFINITY);
+        }
 }
 
 struct Tlas {

@@ -89,6 +89,7 @@ def main():
     p.add_argument("--wild", type=float, default=0.0,
                    help="probability with which each scalar of a scene (placements, camera, field of view, light) is replaced by a special "
                         "value: zeros of either sign, infinities, NaN, 1e30, 1e-30, a denormal, 1e-7, 90/180/360 for angles")
+    p.add_argument("--all-paths", action="store_true", help="plain scenes also through rt_render_frames and rt_render_frame_sampled (RGB)")
     p.add_argument("--instanced", action="store_true",
                    help="lists of 1..40 placed meshes through rt_render_frame_instanced against the reference's loop over the list")
     a = p.parse_args()
@@ -137,6 +138,16 @@ def main():
         rgb, hid, ht, sh = ctx.render_host(cam, light, ctfs, w, h)
         same = (np.array_equal(hid, want.hit_id) and np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32))
                 and np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb))
+        if same and a.all_paths:
+            # the throughput kernel (two frames in one launch) and the sampled kernel at one sample and one light
+            import torch
+            two = torch.empty((2, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            smp = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+            ctx.render_frames(cam, light, [ctfs, ctfs], w, h, two)
+            ctx.render_sampled(cam, [light], ctfs, w, h, 1, 0, smp)
+            ctx.sync()
+            same = (np.array_equal(two[0].cpu().numpy(), want.rgb) and np.array_equal(two[1].cpu().numpy(), want.rgb)
+                    and np.array_equal(smp.cpu().numpy(), want.rgb))
         if not same:
             print(json.dumps({"scene": k, "seed": a.seed, "size": [w, h], "ids_differ": int((hid != want.hit_id).sum()),
                               "t_differ": int((ht.view(np.uint32) != want.hit_t.view(np.uint32)).sum()),

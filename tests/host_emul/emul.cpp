@@ -40,6 +40,7 @@ struct EmulScene {
     int stack_high = 0;
     bool regroup = false;
     bool keep_hierarchy = false;       // instanced frames: the product's hierarchy kept from call to call
+    float box_allowance = 0.0f;        // what the world boxes were widened by last time
     uint32_t* work_plane = nullptr;    // instanced frames: per pixel {box tests, triangle tests} of both rays, when set
     StandingTlas standing;
     int hierarchy_reused = 0;          // calls that reused the kept tree
@@ -270,6 +271,8 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
         fill_placement(tfs[i], A, M);
         if (!M.empty) { boxes.push_back(instance_box(tfs[i], M.root_min, M.root_max)); ids.push_back((uint32_t)i); }
     }
+    s->box_allowance = settled_allowance(s->box_allowance, scene_box_allowance(boxes, A.cam_pos));
+    widen_boxes(boxes, s->box_allowance);
     Tlas T;
     if (s->keep_hierarchy) s->hierarchy_reused += s->standing.update(boxes, ids, (size_t)n_inst, T) ? 1 : 0;
     else TlasBuilder(boxes, ids, T).run();

@@ -231,6 +231,41 @@ def test_entries_with_nan_and_infinite_placements(po, meshes, em_default):
     assert n == 15
 
 
+def far_entries_scene(po):
+    """Entries placed at +-1e30 among ordinary ones, the light straight along z (two components of -0), found by
+    scripts/soak_parity.py --instanced --wild: the reference's test in the space of an entry at 1e30 works on ray origins of that
+    size, accepts and rejects by rounding alone, and its shadow rays -- which start ON such entries or head for one 1e30
+    away -- do the same against every other entry.  The world boxes of the hierarchy have to allow for that."""
+    P = [(0.04725063592195511, 180.0, 0.6031175255775452, 3.033522605895996, 0.7726259827613831, 0.7332237958908081),
+         (0.6915498971939087, -0.23808303475379944, 0.10843290388584137, 2.77695369720459, -2.682859182357788, -2.1754519939422607),
+         (-0.3740750849246979, -0.014469670131802559, 1.0, 180.0, -2.951401948928833, 2.185908317565918),
+         (1.0000000150474662e+30, 0.021858487278223038, -1.0000000116860974e-07, 0.843559741973877, 1.5415972471237183, -0.29535576701164246),
+         (0.6323668360710144, 0.12587839365005493, -0.7777173519134521, -0.9772530198097229, -0.21872852742671967, -0.01635465957224369),
+         (-0.0, 1.0000000150474662e+30, -0.20492178201675415, -3.199599027633667, 0.4215320646762848, -1.234921932220459),
+         (-0.7121354341506958, 0.2877514064311981, 1.0005271035279194e-42, -1.2818286418914795, 2.015014410018921, 0.4149746596813202),
+         (-1.0000000150474662e+30, -0.8866188526153564, 0.005409448407590389, 0.5089237093925476, 3.1592581272125244, 0.6291816830635071),
+         (-0.5967709422111511, 0.5279380083084106, 1.0000000150474662e+30, 360.0, 2.010882616043091, -0.8510827422142029),
+         (-0.8242605924606323, 0.34832876920700073, 0.895243227481842, -2.056257724761963, 1.580925703048706, 0.42089763283729553),
+         (0.7087642550468445, 0.2895757257938385, -0.6899518966674805, -0.09705236554145813, 2.2009589672088623, 0.0),
+         (0.809302568435669, -0.467088907957077, 0.7051159143447876, 3.0222854614257812, -2.380211353302002, 0.9157808423042297),
+         (-0.8258883953094482, 0.7905725240707397, 0.16452465951442719, -0.8904184103012085, -2.445004940032959, 2.401196002960205),
+         (-0.19392336905002594, 0.10682975500822067, 0.7816780805587769, -2.6532580852508545, 0.856707751750946, -0.7455148696899414),
+         (-0.9212556481361389, 0.9470036029815674, 0.4442795515060425, 0.39398717880249023, 3.02315354347229, 1.388624668121338)]
+    ids = [1, 1, 2, 0, 1, 2, 1, 1, 1, 1, 2, 0, 0, 0, 2]
+    tfs = [po.Transform(po.vec3(*p[:3]), po.vec3(*p[3:])) for p in P]
+    cam = po.Camera(po.vec3(1.0005271035279194e-42, -3.171860456466675, 1.9991309642791748),
+                    po.vec3(-0.8964948654174805, 0.5784764289855957, 1.0005271035279194e-42), po.vec3(0, 1, 0), 68.18736359411977)
+    light = po.Light(po.vec3(-0.0, -0.0, 1.6980289220809937), po.vec3(0.04442866891622543, -0.10858384519815445, 0.8541004061698914))
+    return ids, tfs, cam, light
+
+
+def test_entries_at_1e30_do_not_escape_the_hierarchy(po, meshes, em_default):
+    ids, tfs, cam, light = far_entries_scene(po)
+    fr, inst, tri = oracle_planes(po, meshes, ids, tfs, cam, light, 200, 40)
+    check(em_default.render_instanced(cam, light, ids, tfs, 200, 40), fr, inst, tri)
+    assert (fr.shadow == 1).sum() > 2000
+
+
 def test_no_instances_is_background(po, em_default):
     got = em_default.render_instanced(po.default_camera(), po.default_light(), [], [], 16, 9)
     assert (got["rgb"] == 50).all() and (got["hit_inst"] == -1).all() and (got["shadow"] == 255).all()
@@ -443,3 +478,20 @@ def test_gpu_entries_with_nan_and_infinite_placements(gscene, po, meshes):
     for name, ids, tfs in nonfinite_lists(po):
         fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), 96, 54)
         check(gpu_render(gscene, po, ids, tfs, 96, 54), fr, inst, tri)
+
+
+@pytest.mark.gpu
+def test_gpu_entries_at_1e30_do_not_escape_the_hierarchy(gscene, po, meshes):
+    import torch
+    from raytracer_amd import capi
+    ids, tfs, cam, l = far_entries_scene(po)
+    fr, inst, tri = oracle_planes(po, meshes, ids, tfs, cam, l, 200, 40)
+    ccam = capi.Camera(capi.Vec3(*cam.position.tup()), capi.Vec3(*cam.look_at.tup()), capi.Vec3(*cam.up.tup()), cam.fov)
+    light = capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
+    lst = capi.Context.make_instances(ids, [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in tfs])
+    rgb = torch.empty((40, 200, 3), dtype=torch.uint8, device="cuda:0")
+    hi = torch.empty((40, 200), dtype=torch.int32, device="cuda:0")
+    sh = torch.empty((40, 200), dtype=torch.uint8, device="cuda:0")
+    gscene.render_instanced(ccam, light, lst, 200, 40, rgb, hit_instance=hi, shadow=sh)
+    gscene.sync()
+    assert np.array_equal(hi.cpu().numpy(), inst) and np.array_equal(sh.cpu().numpy(), fr.shadow) and np.array_equal(rgb.cpu().numpy(), fr.rgb)
