@@ -82,6 +82,78 @@ def instanced(a):
     ctx.close()
 
 
+def soups(a):
+    """Random triangle soups (1..400 triangles, sometimes flat, sometimes many identical) whose vertex, texture and normal values are
+    replaced with probability --wild by special values: built on the host (against the oracle's build, bit for bit) and on the
+    device, packed on the host and on the device, rendered in both traversal modes against the oracle's reference loop."""
+    import torch  # noqa: F401
+    from oracle import pyoracle as po
+    from raytracer_amd import capi
+    po.lib()
+    rng = np.random.default_rng(a.seed)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e30, -1e30, 1e-30, 1e-42, 1e-7, -1e-7, 1.0, 3e38, -3e38], np.float32)
+    tex = rng.integers(0, 256, size=(8, 8, 4), dtype=np.uint8)
+    l = po.default_light()
+    light = capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    pixels = hits = 0
+    w, h = 96, 54
+    for k in range(a.scenes):
+        n = int(rng.choice([1, 2, 5, 17, 64, 150, 400]))
+        soup = (rng.normal(size=(n, 24)) * rng.choice([0.3, 1.0, 3.0])).astype(np.float32)
+        kind = rng.integers(4)
+        if kind == 1:
+            soup[:, [1, 4, 7]] = np.float32(0.25)                       # flat in y
+        elif kind == 2:
+            soup[n // 3:, :9] = soup[0, :9]                               # many identical triangles: partitions that fail
+        mask = rng.uniform(size=soup.shape) < a.wild
+        soup[mask] = rng.choice(special, size=int(mask.sum()))
+        # vertices get no finite giants: with coordinates of 1e30 .. 3e38 the products of ray.c:46-62 overflow, u comes out as
+        # inf - inf = NaN, passes every comparison (they are all false), and the reference accepts the hit with a finite t --
+        # and then indexes its texture with (int)NaN.  NaN and infinite coordinates never get that far (t is NaN or 0).
+        pos = soup[:, :9]
+        giant = np.isfinite(pos) & (np.abs(pos) > 1e20)
+        pos[giant] = np.float32(np.inf)
+        # texture coordinates stay finite: with a NaN or infinite one the reference computes (int)(NaN * (size - 1)) and reads
+        # the texture far out of bounds (mesh.c:143-147) -- there is no result to compare with
+        uv = soup[:, 9:15]
+        uv[~np.isfinite(uv)] = np.float32(1e30)
+        t, nodes = capi.build_bvh(soup)
+        wt, wn = po.build_bvh(soup)
+        same = np.array_equal(t.view(np.uint32), wt.view(np.uint32)) and nodes.tobytes() == wn.tobytes()
+        tf = po.Transform(po.vec3(*rng.uniform(-0.5, 0.5, 3)), po.vec3(*rng.uniform(-3.2, 3.2, 3)))
+        ctf = [capi.Transform(capi.Vec3(*tf.position.tup()), capi.Vec3(*tf.rotation.tup()))]
+        what = "host build"
+        if same:
+            want = po.render_frame([po.HostMesh(wt, wn, tex)], [tf], po.default_camera(), l, w, h)
+            for route in ("host", "device"):
+                with capi.Context(0) as c:
+                    if route == "host":
+                        c.upload_mesh(t, nodes, tex)
+                    else:
+                        c.set_option("device_build_min", 1)
+                        _, post = c.upload_soup(soup, tex, want_triangles=True)
+                        same = same and np.array_equal(post.view(np.uint32), wt.view(np.uint32))
+                    for flags in (0, capi.RT_FLAG_REFERENCE_ORDER):
+                        rgb, hid, ht, sh = c.render_host(cam, light, ctf, w, h, flags=flags)
+                        same = (same and np.array_equal(hid, want.hit_id) and np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32))
+                                and np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb))
+                if not same:
+                    what = f"{route} route"
+                    break
+        if not same:
+            np.save(os.path.join(REPO, "gpurun_out", f"soup_fail_{a.seed}_{k}.npy"), soup)
+            print(json.dumps({"scene": k, "seed": a.seed, "triangles": n, "differs": what,
+                              "placement": [repr(v) for v in tf.position.tup() + tf.rotation.tup()]}))
+            sys.exit(1)
+        pixels += w * h
+        hits += int((want.hit_id >= 0).sum())
+        if (k + 1) % 100 == 0:
+            print(f"[soak] {k + 1} soups identical", file=sys.stderr, flush=True)
+    print(json.dumps({"scenes": a.scenes, "seed": a.seed, "path": "random soups: rt_bvh_build, rt_mesh_upload / rt_mesh_upload_soup (device build and "
+                      "packing), rt_render_frame in both traversal modes", "pixels": pixels, "pixels_with_a_hit": hits, "identical": True, "wild": a.wild}))
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--scenes", type=int, default=500)
@@ -92,9 +164,12 @@ def main():
     p.add_argument("--all-paths", action="store_true", help="plain scenes also through rt_render_frames and rt_render_frame_sampled (RGB)")
     p.add_argument("--instanced", action="store_true",
                    help="lists of 1..40 placed meshes through rt_render_frame_instanced against the reference's loop over the list")
+    p.add_argument("--soups", action="store_true", help="random triangle soups with special values among their numbers, both builders and packers")
     a = p.parse_args()
     if a.instanced:
         return instanced(a)
+    if a.soups:
+        return soups(a)
     import torch  # noqa: F401  (its HIP runtime first)
     from oracle import pyoracle as po
     from raytracer_amd import capi
