@@ -154,6 +154,84 @@ def soups(a):
                       "packing), rt_render_frame in both traversal modes", "pixels": pixels, "pixels_with_a_hit": hits, "identical": True, "wild": a.wild}))
 
 
+def multi(a):
+    """Scenes of one to six random soups (as in --soups) under random placements, cameras and lights: between-mesh ties, screen and
+    shadow rectangles of boxes with infinite or NaN bounds, scene bounds that are infinite.  rt_render_frame in both traversal
+    modes, rt_render_frames, and the same list through rt_render_frame_instanced, against the oracle's reference loop."""
+    import torch
+    from oracle import pyoracle as po
+    from raytracer_amd import capi
+    po.lib()
+    rng = np.random.default_rng(a.seed)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e30, -1e30, 1e-30, 1e-42, 1e-7, -1e-7, 1.0, 3e38, -3e38], np.float32)
+    tex = rng.integers(0, 256, size=(8, 8, 4), dtype=np.uint8)
+    pixels = hits = 0
+    w, h = 96, 54
+    for k in range(a.scenes):
+        m = int(rng.integers(1, 7))
+        built, tfs = [], []
+        for _ in range(m):
+            n = int(rng.choice([1, 2, 5, 17, 64, 150]))
+            soup = (rng.normal(size=(n, 24)) * rng.choice([0.3, 1.0, 3.0])).astype(np.float32)
+            kind = rng.integers(4)
+            if kind == 1:
+                soup[:, [1, 4, 7]] = np.float32(0.25)
+            elif kind == 2 and rng.uniform() < 0.5:
+                soup[:, :9] = built[-1][0][: n, :9] if built and built[-1][0].shape[0] >= n else soup[:, :9]      # coincident with the previous mesh
+            mask = rng.uniform(size=soup.shape) < a.wild
+            soup[mask] = rng.choice(special, size=int(mask.sum()))
+            uv = soup[:, 9:15]
+            uv[~np.isfinite(uv)] = np.float32(1e30)
+            pos = soup[:, :9]
+            pos[np.isfinite(pos) & (np.abs(pos) > 1e20)] = np.float32(np.inf)
+            built.append(po.build_bvh(soup))
+            same_place = tfs and rng.uniform() < 0.2
+            tfs.append(tfs[-1] if same_place else po.Transform(po.vec3(*rng.uniform(-1.5, 1.5, 3)), po.vec3(*rng.uniform(-3.2, 3.2, 3))))
+        eye = rng.uniform(-4, 4, 3)
+        ocam = po.Camera(po.vec3(*eye), po.vec3(*rng.uniform(-1, 1, 3)), po.vec3(0, 1, 0), float(rng.uniform(20, 110)))
+        olight = po.lib().orc_make_light(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(0.3, 1.6, 3)))
+        cam = capi.Camera(capi.Vec3(*ocam.position.tup()), capi.Vec3(*ocam.look_at.tup()), capi.Vec3(0, 1, 0), ocam.fov)
+        light = capi.Light(capi.Vec3(*olight.direction.tup()), capi.Vec3(*olight.color.tup()))
+        meshes = [po.HostMesh(t, nd, tex) for t, nd in built]
+        _, inst, tri = po.render_frame_ids(meshes, tfs, ocam, olight, w, h)
+        fr = po.render_frame(meshes, tfs, ocam, olight, w, h)
+        ctf = [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in tfs]
+        what = None
+        with capi.Context(0) as c:
+            for t, nd in built:
+                c.upload_mesh(t, nd, tex)
+            for flags in (0, capi.RT_FLAG_REFERENCE_ORDER):
+                rgb, hid, ht, sh = c.render_host(cam, light, ctf, w, h, flags=flags)
+                if not (np.array_equal(hid, fr.hit_id) and np.array_equal(ht.view(np.uint32), fr.hit_t.view(np.uint32))
+                        and np.array_equal(sh, fr.shadow) and np.array_equal(rgb, fr.rgb)):
+                    what = what or f"rt_render_frame flags {flags}"
+            two = torch.empty((2, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            ins = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+            hi = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+            htri = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+            c.render_frames(cam, light, [ctf, ctf], w, h, two)
+            c.render_instanced(cam, light, capi.Context.make_instances(list(range(m)), ctf), w, h, ins, hit_instance=hi, hit_tri=htri)
+            c.sync()
+            if what is None and not (np.array_equal(two[0].cpu().numpy(), fr.rgb) and np.array_equal(two[1].cpu().numpy(), fr.rgb)):
+                what = "rt_render_frames"
+            if what is None and not (np.array_equal(ins.cpu().numpy(), fr.rgb) and np.array_equal(hi.cpu().numpy(), inst) and np.array_equal(htri.cpu().numpy(), tri)):
+                what = "rt_render_frame_instanced"
+        if what:
+            np.savez(os.path.join(REPO, "gpurun_out", f"multi_fail_{a.seed}_{k}.npz"), **{f"tris{i}": b[0] for i, b in enumerate(built)},
+                     **{f"nodes{i}": b[1] for i, b in enumerate(built)})
+            print(json.dumps({"scene": k, "seed": a.seed, "meshes": m, "differs": what,
+                              "placements": [[repr(v) for v in t.position.tup() + t.rotation.tup()] for t in tfs],
+                              "camera": [repr(v) for v in ocam.position.tup() + ocam.look_at.tup()] + [repr(ocam.fov)],
+                              "light": [repr(v) for v in olight.direction.tup() + olight.color.tup()]}))
+            sys.exit(1)
+        pixels += w * h
+        hits += int((fr.hit_id >= 0).sum())
+        if (k + 1) % 100 == 0:
+            print(f"[soak] {k + 1} scenes of several soups identical", file=sys.stderr, flush=True)
+    print(json.dumps({"scenes": a.scenes, "seed": a.seed, "path": "one to six random soups per scene: rt_render_frame in both traversal modes, rt_render_frames, "
+                      "rt_render_frame_instanced", "pixels": pixels, "pixels_with_a_hit": hits, "identical": True, "wild": a.wild}))
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--scenes", type=int, default=500)
@@ -164,12 +242,15 @@ def main():
     p.add_argument("--all-paths", action="store_true", help="plain scenes also through rt_render_frames and rt_render_frame_sampled (RGB)")
     p.add_argument("--instanced", action="store_true",
                    help="lists of 1..40 placed meshes through rt_render_frame_instanced against the reference's loop over the list")
+    p.add_argument("--multi", action="store_true", help="scenes of one to six random soups through the plain, batched and instanced frame paths")
     p.add_argument("--soups", action="store_true", help="random triangle soups with special values among their numbers, both builders and packers")
     a = p.parse_args()
     if a.instanced:
         return instanced(a)
     if a.soups:
         return soups(a)
+    if a.multi:
+        return multi(a)
     import torch  # noqa: F401  (its HIP runtime first)
     from oracle import pyoracle as po
     from raytracer_amd import capi
