@@ -239,6 +239,7 @@ def main():
     p.add_argument("--wild", type=float, default=0.0,
                    help="probability with which each scalar of a scene (placements, camera, field of view, light) is replaced by a special "
                         "value: zeros of either sign, infinities, NaN, 1e30, 1e-30, a denormal, 1e-7, 90/180/360 for angles")
+    p.add_argument("--spp", type=int, default=1, help="plain scenes also through rt_render_frame_sampled with this many samples and a second light")
     p.add_argument("--all-paths", action="store_true", help="plain scenes also through rt_render_frames and rt_render_frame_sampled (RGB)")
     p.add_argument("--instanced", action="store_true",
                    help="lists of 1..40 placed meshes through rt_render_frame_instanced against the reference's loop over the list")
@@ -304,6 +305,17 @@ def main():
             ctx.sync()
             same = (np.array_equal(two[0].cpu().numpy(), want.rgb) and np.array_equal(two[1].cpu().numpy(), want.rgb)
                     and np.array_equal(smp.cpu().numpy(), want.rgb))
+        if same and a.spp > 1:
+            # several samples and a second light against the CPU restatement (unpinned by the reference beyond one sample, one light)
+            import torch
+            second = po.Light(po.vec3(*wild(rng.normal(size=3))), po.vec3(*wild(rng.uniform(-0.5, 2.0, 3))))
+            wants = po.render_frame_sampled(meshes, tfs, ocam, [olight, second], a.spp, k, w, h)
+            smp = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+            sid = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+            ctx.set_option("sampled_split", k % 2)
+            ctx.render_sampled(cam, [light, capi.Light(capi.Vec3(*second.direction.tup()), capi.Vec3(*second.color.tup()))], ctfs, w, h, a.spp, k, smp, hit_id=sid)
+            ctx.sync()
+            same = np.array_equal(smp.cpu().numpy(), wants.rgb) and np.array_equal(sid.cpu().numpy(), wants.hit_id)
         if not same:
             print(json.dumps({"scene": k, "seed": a.seed, "size": [w, h], "ids_differ": int((hid != want.hit_id).sum()),
                               "t_differ": int((ht.view(np.uint32) != want.hit_t.view(np.uint32)).sum()),
