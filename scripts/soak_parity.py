@@ -239,6 +239,7 @@ def main():
     p.add_argument("--wild", type=float, default=0.0,
                    help="probability with which each scalar of a scene (placements, camera, field of view, light) is replaced by a special "
                         "value: zeros of either sign, infinities, NaN, 1e30, 1e-30, a denormal, 1e-7, 90/180/360 for angles")
+    p.add_argument("--full-size", action="store_true", help="plain scenes at 1920x1080, 1280x720, 3840x2160 and 1917x1083 instead of small frames")
     p.add_argument("--spp", type=int, default=1, help="plain scenes also through rt_render_frame_sampled with this many samples and a second light")
     p.add_argument("--all-paths", action="store_true", help="plain scenes also through rt_render_frames and rt_render_frame_sampled (RGB)")
     p.add_argument("--instanced", action="store_true",
@@ -262,6 +263,8 @@ def main():
         ctx.upload_mesh(m.tris, m.nodes, m.rgba)
     rng = np.random.default_rng(a.seed)
     sizes = [(160, 90), (200, 120), (97, 61), (33, 130), (256, 8)]
+    if a.full_size:
+        sizes = [(1920, 1080), (1280, 720), (3840, 2160), (1917, 1083)]
     pixels = hits = 0
     special = [0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e30, -1e30, 1e-30, 1e-42, 1e-7, -1e-7, 1.0, 90.0, 180.0, 360.0]
 
