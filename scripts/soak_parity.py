@@ -35,11 +35,30 @@ def instanced(a):
     def wild(values):
         return tuple(float(rng.choice(special)) if rng.uniform() < a.wild else float(v) for v in values)
 
+    prev_view = None
     for k in range(a.scenes):
-        n = int(rng.integers(1, 41))
-        spread = float(rng.choice([1.0, 3.0, 8.0]))
-        ids = [int(rng.choice([0, 1, 1, 1, 2])) for _ in range(n)]
-        tfs = [po.Transform(po.vec3(*wild(rng.uniform(-spread, spread, 3))), po.vec3(*wild(rng.uniform(-3.2, 3.2, 3)))) for _ in range(n)]
+        if a.mutate and k % 40 != 0:
+            # the previous list with a few entries moved, swapped for another mesh, or the list one entry longer or shorter:
+            # the kept hierarchy is patched, placement constants of the others are reused
+            ids, tfs = list(ids), list(tfs)
+            for _ in range(int(rng.integers(1, 5))):
+                j = int(rng.integers(len(ids)))
+                what = rng.integers(4)
+                if what == 0:
+                    ids[j] = int(rng.choice([0, 1, 2]))
+                elif what == 1 and len(ids) > 2:
+                    del ids[j]; del tfs[j]
+                elif what == 2 and len(ids) < 60:
+                    ids.append(int(rng.choice([0, 1, 2])))
+                    tfs.append(po.Transform(po.vec3(*wild(rng.uniform(-spread, spread, 3))), po.vec3(*wild(rng.uniform(-3.2, 3.2, 3)))))
+                else:
+                    tfs[j] = po.Transform(po.vec3(*wild(rng.uniform(-spread, spread, 3))), po.vec3(*wild(rng.uniform(-3.2, 3.2, 3))))
+            n = len(ids)
+        else:
+            n = int(rng.integers(1, 41))
+            spread = float(rng.choice([1.0, 3.0, 8.0]))
+            ids = [int(rng.choice([0, 1, 1, 1, 2])) for _ in range(n)]
+            tfs = [po.Transform(po.vec3(*wild(rng.uniform(-spread, spread, 3))), po.vec3(*wild(rng.uniform(-3.2, 3.2, 3)))) for _ in range(n)]
         if n > 3 and rng.uniform() < 0.3:                       # coincident entries: the earlier one wins
             tfs[n - 1] = tfs[0]; ids[n - 1] = ids[0]
         eye = rng.uniform(-1.2 * spread - 2, 1.2 * spread + 2, 3)
@@ -54,6 +73,9 @@ def instanced(a):
             olight = po.lib().orc_make_light(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(0.3, 1.6, 3)))
         cam = capi.Camera(capi.Vec3(*ocam.position.tup()), capi.Vec3(*ocam.look_at.tup()), capi.Vec3(*ocam.up.tup()), fov)
         light = capi.Light(capi.Vec3(*olight.direction.tup()), capi.Vec3(*olight.color.tup()))
+        if a.mutate and k % 40 != 0 and prev_view is not None and rng.uniform() < 0.7:
+            ocam, olight, cam, light = prev_view                # same camera and light as the step before: constants are reused
+        prev_view = (ocam, olight, cam, light)
         w, h = sizes[k % len(sizes)]
         fr, inst, tri = po.render_frame_ids([meshes[i] for i in ids], tfs, ocam, olight, w, h)
         lst = capi.Context.make_instances(ids, [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in tfs])
@@ -232,6 +254,72 @@ def multi(a):
                       "rt_render_frame_instanced", "pixels": pixels, "pixels_with_a_hit": hits, "identical": True, "wild": a.wild}))
 
 
+def rebuilds(a):
+    """One context, two meshes (the reference's ground and one that keeps changing): every step gives the second mesh a new random
+    soup of 0 .. 30 000 triangles through rt_mesh_rebuild (build and packing on the device or on the host, by the size threshold of
+    the step) or through rt_bvh_build + rt_mesh_replace, then renders (plain frame, batched frames, instanced list) against the
+    oracle's reference loop over the oracle's own build of the same soup.  Device arrays are reused or replaced as sizes come and go."""
+    import torch
+    from oracle import pyoracle as po
+    from raytracer_amd import capi
+    po.lib()
+    rng = np.random.default_rng(a.seed)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-30, 1e-42, 1e-7, -1e-7, 1.0], np.float32)
+    ground = po.default_meshes()[2]
+    tex = rng.integers(0, 256, size=(8, 8, 4), dtype=np.uint8)
+    w, h = 96, 54
+    l = po.default_light()
+    light = capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    pixels = hits = 0
+    with capi.Context(0) as c:
+        c.upload_mesh(ground.tris, ground.nodes, ground.rgba)
+        c.upload_soup((rng.normal(size=(5, 24))).astype(np.float32), tex)
+        for k in range(a.scenes):
+            n = int(rng.choice([0, 1, 3, 4, 5, 50, 300, 300, 2000, 30000], p=[.05, .1, .1, .1, .1, .15, .15, .1, .1, .05]))
+            soup = (rng.normal(size=(n, 24)) * rng.choice([0.3, 1.0])).astype(np.float32)
+            soup[:, :9] = soup[:, :9] * np.float32(0.2) + np.repeat(rng.normal(size=(n, 3)).astype(np.float32) * np.float32(0.8), 3, axis=1).reshape(n, 9)[:, [0, 3, 6, 1, 4, 7, 2, 5, 8]]
+            mask = rng.uniform(size=soup.shape) < a.wild
+            soup[mask] = rng.choice(special, size=int(mask.sum()))
+            uv = soup[:, 9:15]
+            uv[~np.isfinite(uv)] = np.float32(1e30)
+            wt, wn = po.build_bvh(soup)
+            route = int(rng.integers(3))
+            if route == 0:
+                c.set_option("device_build_min", 1)
+                post = c.rebuild_mesh(1, soup, want_triangles=True)
+            elif route == 1:
+                c.set_option("device_build_min", 1 << 30)
+                post = c.rebuild_mesh(1, soup, want_triangles=True)
+            else:
+                post, nodes = capi.build_bvh(soup)
+                c.replace_mesh(1, post, nodes)
+            same = np.array_equal(np.asarray(post).view(np.uint32), wt.view(np.uint32))
+            tfs = [po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0)), po.Transform(po.vec3(*rng.uniform(-0.5, 0.5, 3) + [0, 0.8, 0]), po.vec3(*rng.uniform(-3.2, 3.2, 3)))]
+            ctf = [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in tfs]
+            want = po.render_frame([ground, po.HostMesh(wt, wn, tex)], tfs, po.default_camera(), l, w, h)
+            rgb, hid, ht, sh = c.render_host(cam, light, ctf, w, h)
+            two = torch.empty((2, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            ins = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+            c.render_frames(cam, light, [ctf, ctf], w, h, two)
+            c.render_instanced(cam, light, capi.Context.make_instances([0, 1, 1], ctf + [ctf[1]]), w, h, ins)
+            c.sync()
+            same = (same and np.array_equal(hid, want.hit_id) and np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32))
+                    and np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb) and np.array_equal(two[1].cpu().numpy(), want.rgb)
+                    and np.array_equal(ins.cpu().numpy(), want.rgb))
+            if not same:
+                np.save(os.path.join(REPO, "gpurun_out", f"rebuild_fail_{a.seed}_{k}.npy"), soup)
+                print(json.dumps({"step": k, "seed": a.seed, "triangles": n, "route": ["rt_mesh_rebuild on the device", "rt_mesh_rebuild on the host", "rt_mesh_replace"][route],
+                                  "differs": True, "placement": [repr(v) for v in tfs[1].position.tup() + tfs[1].rotation.tup()]}))
+                sys.exit(1)
+            pixels += w * h
+            hits += int((want.hit_id >= 0).sum())
+            if (k + 1) % 100 == 0:
+                print(f"[soak] {k + 1} rebuilds identical", file=sys.stderr, flush=True)
+    print(json.dumps({"scenes": a.scenes, "seed": a.seed, "path": "one mesh rebuilt every step (rt_mesh_rebuild on device / host, rt_mesh_replace; 0..30 000 triangles), "
+                      "rt_render_frame, rt_render_frames, rt_render_frame_instanced", "pixels": pixels, "pixels_with_a_hit": hits, "identical": True, "wild": a.wild}))
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--scenes", type=int, default=500)
@@ -244,6 +332,8 @@ def main():
     p.add_argument("--all-paths", action="store_true", help="plain scenes also through rt_render_frames and rt_render_frame_sampled (RGB)")
     p.add_argument("--instanced", action="store_true",
                    help="lists of 1..40 placed meshes through rt_render_frame_instanced against the reference's loop over the list")
+    p.add_argument("--mutate", action="store_true", help="with --instanced: each list is the previous one with a few entries changed (kept hierarchy patched)")
+    p.add_argument("--rebuilds", action="store_true", help="one context whose second mesh gets a new random soup every step (rebuild / replace routes)")
     p.add_argument("--multi", action="store_true", help="scenes of one to six random soups through the plain, batched and instanced frame paths")
     p.add_argument("--soups", action="store_true", help="random triangle soups with special values among their numbers, both builders and packers")
     a = p.parse_args()
@@ -253,6 +343,8 @@ def main():
         return soups(a)
     if a.multi:
         return multi(a)
+    if a.rebuilds:
+        return rebuilds(a)
     import torch  # noqa: F401  (its HIP runtime first)
     from oracle import pyoracle as po
     from raytracer_amd import capi
