@@ -459,6 +459,46 @@ private:
                 }
                 out_.grid[(size_t)iy * (size_t)n + (size_t)ix] = ref;
             }
+        // Where the walk would start at a node (several leaves' boxes overlap the padded cell, which is the rule for the
+        // overlapping leaves the reference's mean split leaves), the cell names those leaves themselves instead: a list of up to
+        // kGridListMax records {leaf box, leaf reference} behind the cells.  A ray whose X lies in the cell can pass no other
+        // leaf's box, and a leaf is reached exactly when its own box is passed (ancestors' boxes contain it), so testing the
+        // listed boxes one by one reaches the leaves the walk would reach -- without the boxes above them.
+        const size_t cells = (size_t)n * (size_t)n, list_base = (cells + 7) & ~(size_t)7;
+        out_.grid.resize(list_base, leaf_ref(0, 0));
+        std::vector<uint32_t> stack;
+        for (int iy = 0; iy < n; iy++)
+            for (int ix = 0; ix < n; ix++) {
+                const uint32_t entry = out_.grid[(size_t)iy * (size_t)n + (size_t)ix];
+                if (entry & kLeafBit) continue;
+                const double rlo[2] = {lo[0] + ix * cs[0] - slack[0], lo[1] + iy * cs[1] - slack[1]};
+                const double rhi[2] = {lo[0] + (ix + 1) * cs[0] + slack[0], lo[1] + (iy + 1) * cs[1] + slack[1]};
+                uint32_t rec[kGridListMax][8];
+                uint32_t count = 0;
+                bool fits = true;
+                stack.assign(1, entry);
+                while (!stack.empty() && fits) {
+                    const PairNode& N = out_.pairs[stack.back()];
+                    stack.pop_back();
+                    for (int side = 0; side < 2 && fits; side++) {
+                        const float* bmin = side ? N.rmin : N.lmin;
+                        const float* bmax = side ? N.rmax : N.lmax;
+                        const uint32_t child = side ? N.rref : N.lref;
+                        if (!overlaps(bmin, bmax, rlo, rhi)) continue;
+                        if (!(child & kLeafBit)) { stack.push_back(child); continue; }
+                        if (((child >> 24) & 0x7Fu) == 0) continue;
+                        if (count == kGridListMax) { fits = false; break; }
+                        memcpy(&rec[count][0], bmin, 12); memcpy(&rec[count][3], bmax, 12);
+                        rec[count][6] = child; rec[count][7] = 0;
+                        count++;
+                    }
+                }
+                const size_t at = (out_.grid.size() - list_base) / 8;
+                if (!fits || at + count > 0x00FFFFFFu) continue;                 // too many leaves: the walk starts at the node as before
+                if (count == 0) { out_.grid[(size_t)iy * (size_t)n + (size_t)ix] = leaf_ref(0, 0); continue; }
+                for (uint32_t c = 0; c < count; c++) out_.grid.insert(out_.grid.end(), &rec[c][0], &rec[c][0] + 8);
+                out_.grid[(size_t)iy * (size_t)n + (size_t)ix] = kGridListBit | (count << 24) | (uint32_t)at;
+            }
         out_.grid_axis = (uint32_t)k; out_.grid_n = n;
         for (int j = 0; j < 2; j++) {
             out_.grid_lo[j] = (float)lo[j];

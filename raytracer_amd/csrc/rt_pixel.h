@@ -256,6 +256,13 @@ RT_HD uint32_t entry_ref(const MeshArgs& M, F3 d) {
     return (d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ? M.root_ref : M.ref_root;
 }
 
+RT_HD float uint_as_f32(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; memcpy(&f, &u, 4); return f;
+#endif
+}
 RT_HD float comp(F3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
 // Where a ray starts its walk in a flat mesh (MeshArgs::grid, built by Packer::build_grid): the node stored for the cell
@@ -298,6 +305,26 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
         // kinds of work on every step.
         uint32_t ref = entry_ref<false>(M, d);
         if (M.grid_axis < 3u && ref == M.root_ref && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ref = grid_entry(M, o, d, inv, ref);
+        if (!(ref & kLeafBit) && (ref & kGridListBit)) {
+            // the cell names its leaves: each one's own box test (the reference reaches a leaf exactly when that passes,
+            // the boxes above contain it), nothing else
+            const uint32_t count = (ref >> 24) & 0xFu;
+            const size_t first = ((((size_t)M.grid_n * (size_t)M.grid_n) + 7) & ~(size_t)7) + (size_t)(ref & 0x00FFFFFFu) * 8;
+            for (uint32_t i = 0; i < count; i++) {
+                float bmin[3], bmax[3];
+                const size_t at = first + (size_t)i * 8;
+                RT_UNROLL
+                for (int c = 0; c < 3; c++) { bmin[c] = uint_as_f32(read_word(M.grid, at + c)); bmax[c] = uint_as_f32(read_word(M.grid, at + 3 + c)); }
+                const uint32_t leaf = read_word(M.grid, at + 6);
+                if (COUNT) work.slabs++;
+                float entry;
+                if (!slab_t(o, inv, bmin, bmax, entry)) continue;
+                if (CULL && entry > q.limit) continue;
+                if (test_leaf<ANY, COUNT, FULL, LB>(M, nodes, leaf, o, d, q, work)) return true;
+            }
+            hit = q.hit;
+            return q.found;
+        }
         bool live = true;
         while (live) {
             auto step = [&](const PairNode& N) {
