@@ -358,7 +358,10 @@ def main():
                 "frac": round(tfl / VALU_PEAK_TFLOPS, 5), "traffic": None, "hbm_frac": None,
                 # the same work against what this instruction stream can issue at most: one rounding per reference operation
                 # means no fused multiply-adds (x1/2) and, but for the slab test, no two-wide packing (x1/2)
-                "unfused_unpacked_peak": round(VALU_PEAK_TFLOPS / 4, 1), "frac_of_unfused_unpacked_peak": round(tfl / (VALU_PEAK_TFLOPS / 4), 4),
+                "unfused_unpacked_peak": round(VALU_PEAK_TFLOPS / 4, 1),
+                # against that ceiling the work the kernel itself executes is what counts (its ordered, culled traversal runs fewer
+                # tests than the reference-equivalent figure above, which can therefore exceed the ceiling)
+                "frac_of_unfused_unpacked_peak": round(float(np.mean(own_flops)) / secs / 1e12 / (VALU_PEAK_TFLOPS / 4), 4),
                 "kernel": "render_batch (block %d), %d frames per launch" % (ctx.get_option("block"), a.batch),
                 "kernel_ms": round(kern_ms, 4), "algorithmic_flops_per_launch": int(np.mean(alg_flops)),
                 "basis": "FLOPs of the reference-equivalent traversal (every box and triangle test scene.c/bvh.c would run: 22 per box "
