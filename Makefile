@@ -5,7 +5,7 @@
 #   make oracle     oracle/liboracle.so and, where /root/reference exists, oracle/_ref/libref.so
 CXX ?= g++
 
-all: product oracle emul examples
+all: product oracle emul examples tools
 
 product:
 	$(MAKE) -C raytracer_amd/csrc
@@ -31,10 +31,16 @@ examples/drone_animation: examples/drone_animation.c raytracer_amd/host/raytrace
 	$(CC) -std=c11 -O2 -Wall -Wextra -D_POSIX_C_SOURCE=200809L -D_DEFAULT_SOURCE -I raytracer_amd/host -o $@ examples/drone_animation.c \
 	    -L raytracer_amd/host -lraytracer_host -Wl,-rpath,'$$ORIGIN/../raytracer_amd/host' -lm
 
+# measurement aids that run on the GPU box (built here, travel with the tree)
+tools: scripts/valu_issue_bench
+
+scripts/valu_issue_bench: scripts/valu_issue_bench.hip
+	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $@ scripts/valu_issue_bench.hip
+
 clean:
 	$(MAKE) -C raytracer_amd/csrc clean
 	$(MAKE) -C raytracer_amd/host clean
 	$(MAKE) -C oracle clean
-	rm -f tests/host_emul/libemul.so tests/host_emul/abi_check examples/drone_animation
+	rm -f tests/host_emul/libemul.so tests/host_emul/abi_check examples/drone_animation scripts/valu_issue_bench
 
-.PHONY: all product oracle emul examples clean
+.PHONY: all product oracle emul examples tools clean

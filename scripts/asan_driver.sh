@@ -10,12 +10,9 @@ set -eu
 cd "$(dirname "$0")/.."
 mkdir -p build/asan
 CL=/opt/rocm/lib/llvm/bin
-F="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt --offload-arch=gfx950 -Xarch_host -fsanitize=address,undefined"
-for f in rt_kernels.hip rt_upscale.hip rt_build.hip rt_host.cpp; do
-    (cd raytracer_amd/csrc && /opt/rocm/bin/hipcc $F -c $f -o ../../build/asan/${f%.*}.o)
-done
+# the C-ABI library through its own Makefile (one object list), host side sanitized, objects kept out of the product's directory
+make -C raytracer_amd/csrc BUILD=../../build/asan OPT="-O1 -g" EXTRA="-Xarch_host -fsanitize=address,undefined"
 cd build/asan
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Xarch_host -fsanitize=address,undefined -o librt_mi355.so rt_kernels.o rt_upscale.o rt_build.o rt_host.o
 rm -f ./*.o
 $CL/clang++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address,undefined -shared -I../../include -o libraytracer_host.so \
     ../../raytracer_amd/host/raytracer_host.cpp ../../raytracer_amd/host/raytracer_math.cpp ../../raytracer_amd/host/webp_anim.cpp \
