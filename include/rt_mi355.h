@@ -75,11 +75,23 @@ typedef struct {
 
 typedef struct rt_ctx rt_ctx;                                     /* opaque */
 
-/* Work counters of one rt_render_frame call made with RT_FLAG_COUNT_WORK. */
+/* Work counters of one rendering call made with RT_FLAG_COUNT_WORK or RT_FLAG_VERIFY_SKIPS. */
 typedef struct {
     uint64_t primary_rays, shadow_rays;     /* rays traced (a ray = one ray against the whole scene) */
-    uint64_t slab_tests, tri_tests;         /* ray/AABB and ray/triangle tests executed */
+    uint64_t slab_tests, tri_tests;         /* ray/AABB and ray/triangle tests executed (RT_FLAG_COUNT_WORK only) */
     uint64_t hit_pixels, shadowed_pixels;
+    /* RT_FLAG_VERIFY_SKIPS only (zero otherwise): shortcut decisions that the kernel examined again the reference's way, and
+     * how many of them the reference's way contradicts -- all of the following must be zero:
+     *   vis_disagreements         a camera ray passes the root box (scene.c:79, bvh.c:82) of a mesh that the screen rectangle of
+     *                             its tile leaves out
+     *   shadow_vis_disagreements  the same for a shadow ray (scene.c:131) and the shadow rectangle
+     *   entry_disagreements       a walk that entered a flat mesh through its grid ends differently from the walk from the root
+     *   cull_disagreements        the ordered, distance-culled walk through the second tree ends differently from the
+     *                             reference's own walk (its tree, every box whose ancestors pass, nothing culled: bvh.c:80-129)
+     *   instance_disagreements    rt_render_frame_instanced: the walk over the instance hierarchy ends differently from the
+     *                             reference's loop over the whole mesh list (scene.c:72-108, 124-139) */
+    uint64_t skip_checks;
+    uint64_t vis_disagreements, shadow_vis_disagreements, entry_disagreements, cull_disagreements, instance_disagreements;
 } rt_counters;
 
 /* ---- context --------------------------------------------------------------------------- */
@@ -139,6 +151,16 @@ int rt_mesh_count(const rt_ctx* ctx);
 /* ---- rendering ------------------------------------------------------------------------- */
 #define RT_FLAG_COUNT_WORK   0x1u   /* also count slab / triangle tests (slower; for measurement) */
 #define RT_FLAG_REFERENCE_ORDER 0x2u /* traverse every box the reference would, no distance culling */
+/* Self-check of everything the kernels skip by geometry.  The frame is rendered as without the flag (one lane per ray), but
+ * wherever a shortcut is taken the kernel ALSO does what the reference would have done and counts the cases in which that
+ * contradicts the shortcut: a mesh left out for a tile by its screen or shadow rectangle gets the reference's root test on
+ * the very ray; every query is walked as rendered (second tree, grid entry of flat meshes, nearer child first, distance
+ * culling, any-hit shadows), again from the root without the grid, and again as bvh.c:80-129 walks it, and the outcomes are
+ * compared; an instanced frame also runs the reference's loop over the whole mesh list per ray.  rt_last_counters reports the
+ * result (all *_disagreements must be zero).  Several times slower; overrides RT_FLAG_COUNT_WORK and
+ * RT_FLAG_REFERENCE_ORDER; accepted by rt_render_frame[_strips], rt_render_frame_sampled[_strips], rt_render_frame_host and
+ * rt_render_frame_instanced[_host] (there the per-ray loop over the list makes it a tool for small frames). */
+#define RT_FLAG_VERIFY_SKIPS 0x4u
 
 /* render_scene (scene.c:52-160) for one frame.  transforms[i] is scene->meshes[i].transform
  * (set_mesh_position / set_mesh_rotation, mesh.c:121-127).  Output planes are device pointers:
@@ -165,16 +187,20 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light
                      const rt_transform* transforms, int32_t n_frames, int32_t n_transforms,
                      int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream);
 
-/* rt_render_frames for callers that cannot allocate device memory while they render (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
- * arguments, same launch, same bytes as rt_render_frames, but the call reaches no allocator: the per-frame constants
- * that rt_render_frames stages in a device buffer of the context go through a file-scope device array of the library
+/* rt_render_frames for callers that cannot allocate device memory while they render (tight serving loops, harnesses that
+ * forbid hipMalloc in the steady state).  It has no counterpart in the reference.  Same arguments, same launch, same bytes
+ * as rt_render_frames with the exact build of the kernels, but the call reaches no allocator: the per-frame constants that
+ * rt_render_frames stages in a device buffer of the context go through a file-scope device array of the library
  * (RT_MAX_BATCH records, 31 616 bytes, held by every GPU the library runs on until the process ends; its address on the
- * context's GPU is looked up by rt_ctx_create).  Conditions: n_frames <= RT_MAX_BATCH (more: RT_ERR_CAPACITY), and
- * the mesh list must not have changed since the last rendering call of this context -- that call put the combined
- * node array on the device; otherwise RT_ERR_UNSUPPORTED and nothing is launched.  All calls on one GPU share the
- * array: calls that overlap on one GPU (different streams, or contexts on the same device) race; calls on one stream
- * are ordered.  Every byte the kernel reads from the array is written by the call itself first. */
+ * context's GPU is looked up by rt_ctx_create).  Conditions: n_frames <= RT_MAX_BATCH (more: RT_ERR_CAPACITY); the mesh
+ * list must not have changed since the last rendering call of this context -- that call put the combined node array on the
+ * device; and option "fast" must be off (the entry point promises rt_render_frames' exact bytes) -- otherwise
+ * RT_ERR_UNSUPPORTED and nothing is launched.  Eager execution only: the call copies the constants from one of the
+ * context's four page-locked staging slots and waits on that slot's event before it reuses it, so it must NOT be made while
+ * `stream` is being captured into a HIP graph (a captured copy would read whatever a later call left in the slot, and an
+ * event wait is illegal under capture).  All calls on one GPU share the array: calls that overlap on one GPU (different
+ * streams, or contexts on the same device) race; calls on one stream are ordered.  Every byte the kernel reads from the array
+ * is written by the call itself first. */
 int rt_render_frames_noalloc(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,
                              const rt_transform* transforms, int32_t n_frames, int32_t n_transforms,
                              int32_t width, int32_t height, void* d_rgb, size_t frame_stride, void* stream);
@@ -222,7 +248,9 @@ int rt_render_frame_sampled_strips(rt_ctx* ctx, const rt_camera* camera, const r
  * frames go through rt_render_frames on each context's own stream; a batch rendered on another GPU is copied to its
  * place by peer-to-peer copies (xGMI between the GPUs of a node) queued behind its kernel, while that GPU's next batch
  * renders; ctxs[0] renders in place.  No collective is involved: the gather is one point-to-point stream per GPU.
- * The call returns when all frames are in d_rgb.  n_frames may be any number (0: nothing to do); with n_ctx = 1 the
+ * The call returns when all frames are in d_rgb, with the calling thread's current device as it found it.  The work runs on
+ * the contexts' own streams and is not ordered against anything else: d_rgb must be idle (nothing of the caller's still
+ * writing or reading it on any stream) when the call is made.  n_frames may be any number (0: nothing to do); with n_ctx = 1 the
  * result is rt_render_frames' over consecutive batches.  Several contexts on the same GPU are allowed (rehearsal).
  * Errors are reported through ctxs[0] (rt_last_error).  rt_device_count: GPUs visible to the process. */
 int rt_render_frames_sharded(rt_ctx* const* ctxs, int32_t n_ctx, const rt_camera* camera, const rt_light* light,

@@ -19,6 +19,7 @@ RT_OK = 0
 RT_ERR_INVALID, RT_ERR_DEVICE, RT_ERR_NO_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_CAPACITY = -1, -2, -3, -4, -5
 RT_FLAG_COUNT_WORK = 0x1
 RT_FLAG_REFERENCE_ORDER = 0x2
+RT_FLAG_VERIFY_SKIPS = 0x4
 RT_MAX_MESHES = 8
 RT_MAX_BATCH = 16
 RT_MAX_LIGHTS = 4
@@ -47,7 +48,9 @@ class Instance(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("primary_rays", "shadow_rays", "slab_tests", "tri_tests", "hit_pixels", "shadowed_pixels")]
+                ("primary_rays", "shadow_rays", "slab_tests", "tri_tests", "hit_pixels", "shadowed_pixels", "skip_checks",
+                 "vis_disagreements", "shadow_vis_disagreements", "entry_disagreements", "cull_disagreements",
+                 "instance_disagreements")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

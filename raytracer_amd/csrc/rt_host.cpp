@@ -685,7 +685,7 @@ int render_frame_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* ligh
     // Work layout: screen rectangles where rays can meet a big mesh are rendered cooperatively and
     // launched first.  Not used when the caller asks for the reference's visiting order or for work
     // counts, when a rectangle cannot be bounded, or when they cover more than a quarter of the frame.
-    if (cfg.variant == 3 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER)) == 0 && ctx->coop) {
+    if (cfg.variant == 3 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER | RT_FLAG_VERIFY_SKIPS)) == 0 && ctx->coop) {
         std::vector<WorldBox> boxes((size_t)n_transforms);
         double slo[3] = {1e300, 1e300, 1e300}, shi[3] = {-1e300, -1e300, -1e300};
         for (int32_t m = 0; m < n_transforms; m++) {
@@ -716,12 +716,12 @@ int render_frame_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* ligh
     O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_id; O.hit_t = (float*)d_hit_t; O.shadow = (uint8_t*)d_shadow;
     O.counters = ctx->d_counters;
     O.tile_clock = (unsigned long long*)ctx->d_tile_clock;
-    if (flags & RT_FLAG_COUNT_WORK) {
+    if (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_VERIFY_SKIPS)) {
         RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DeviceCounters), s));
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    if (cfg.variant == 4 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER)) == 0) {
+    if (cfg.variant == 4 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER | RT_FLAG_VERIFY_SKIPS)) == 0) {
         const size_t pixels = (size_t)width * (size_t)height;
         if (pixels > ctx->defer_capacity) {
             RT_HIP(ctx, hipDeviceSynchronize());          // an earlier frame may still be reading the old list
@@ -736,7 +736,8 @@ int render_frame_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* ligh
         cfg.parity = (int)(ctx->two_pass_frames++ & 1u);
         A.defer_budget = ctx->budget;
     }
-    hipError_t le = ctx->fast ? rt_fast_launch_render(&A, &S, &O, &cfg, s) : launch_render(A, S, O, cfg, s);
+    // the self-check compares against the reference's own arithmetic: it always runs the exact build
+    hipError_t le = ctx->fast && !(flags & RT_FLAG_VERIFY_SKIPS) ? rt_fast_launch_render(&A, &S, &O, &cfg, s) : launch_render(A, S, O, cfg, s);
     if (le != hipSuccess) {
         // leave the work-distribution words of the persistent / two-pass variants in their idle state
         (void)hipDeviceSynchronize();
@@ -811,6 +812,7 @@ int render_frames_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* lig
             return fail(ctx, RT_ERR_UNSUPPORTED, "the mesh list changed since the last rendering call: its node array is not on the device yet "
                                                  "(render once through an allocating entry point, e.g. rt_render_frames, first)");
         if ((size_t)n_frames * sizeof(FrameArgs) > batch_scratch_bytes()) return fail(ctx, RT_ERR_CAPACITY, "batch larger than the static staging array");
+        if (ctx->fast) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_render_frames_noalloc renders rt_render_frames' exact bytes: switch option \"fast\" off");
     } else {
         int cst = commit_scene(ctx);
         if (cst != RT_OK) return cst;
@@ -913,7 +915,7 @@ int render_sampled_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* li
     OutputPlanes O;
     O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_id; O.hit_t = nullptr; O.shadow = nullptr;
     O.counters = ctx->d_counters; O.tile_clock = nullptr;
-    if (flags & RT_FLAG_COUNT_WORK) {
+    if (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_VERIFY_SKIPS)) {
         RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DeviceCounters), s));
         ctx->counters_pending = true;
     }
@@ -1019,13 +1021,14 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
     InstancedArgs I;
     I.inst = reinterpret_cast<const MeshArgs*>(d);
     I.n_inst = (int32_t)ids.size();
+    I.n_total = n_instances;
     I.tlas_root = direct_ref(T, T.root_ref);
     I.tlas = reinterpret_cast<const PairNode*>(d + off_pairs);
     memcpy(I.root_min, T.root_min, 12); memcpy(I.root_max, T.root_max, 12);
     OutputPlanes O;
     O.rgb = (uint8_t*)d_rgb; O.hit_id = (int32_t*)d_hit_instance; O.hit_t = (float*)d_hit_t; O.shadow = (uint8_t*)d_shadow;
     O.counters = ctx->d_counters; O.tile_clock = nullptr;
-    if (flags & RT_FLAG_COUNT_WORK) {
+    if (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_VERIFY_SKIPS)) {
         RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DeviceCounters), s));
         ctx->counters_pending = true;
     }
@@ -1046,6 +1049,8 @@ int rt_render_frames_sharded(rt_ctx* const* ctxs, int32_t n_ctx, const rt_camera
     rt_ctx* root = ctxs[0];
     if (!camera || !light || !d_rgb) return fail(root, RT_ERR_INVALID, "camera, light and d_rgb are required");
     if (n_frames < 0) return fail(root, RT_ERR_INVALID, "negative frame count");
+    int callers_device = -1;                                         // put back before returning
+    if (hipGetDevice(&callers_device) != hipSuccess) { (void)hipGetLastError(); callers_device = -1; }
     if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(root, RT_ERR_INVALID, "bad frame size");
     const size_t image = (size_t)width * (size_t)height * 3;
     if (frame_stride < image) return fail(root, RT_ERR_INVALID, "frame_stride smaller than one image");
@@ -1085,7 +1090,6 @@ int rt_render_frames_sharded(rt_ctx* const* ctxs, int32_t n_ctx, const rt_camera
             if (r == 0) {
                 status = rt_render_frames(c, camera, light, tf.data(), nb, n_transforms, width, height, out + (size_t)first * frame_stride,
                                           frame_stride * (size_t)n_ctx, nullptr);
-                if (status != RT_OK && c != root) root->err = c->err;
                 continue;
             }
             const int slot = round & 1;
@@ -1117,7 +1121,7 @@ int rt_render_frames_sharded(rt_ctx* const* ctxs, int32_t n_ctx, const rt_camera
         ctxs[r]->shard_used[0] = ctxs[r]->shard_used[1] = false;
         if (e != hipSuccess && status == RT_OK) status = hip_fail(root, e, "waiting for a GPU of the sharded frame loop");
     }
-    (void)hipSetDevice(root->device);
+    (void)hipSetDevice(callers_device >= 0 ? callers_device : root->device);
     return status;
 }
 
@@ -1135,7 +1139,7 @@ int rt_render_frame_host(rt_ctx* ctx, const rt_camera* camera, const rt_light* l
     if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 30) return fail(ctx, RT_ERR_INVALID, "bad frame size");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t pixels = (size_t)width * (size_t)height;
-    if (ctx->frames_in_flight > 1 && !h_hit_id && !h_hit_t && !h_shadow && (flags & RT_FLAG_COUNT_WORK) == 0)
+    if (ctx->frames_in_flight > 1 && !h_hit_id && !h_hit_t && !h_shadow && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_VERIFY_SKIPS)) == 0)
         return render_frame_in_flight(ctx, camera, light, transforms, n_transforms, width, height, flags, h_rgb);
     int st = ensure_planes(ctx, pixels);
     if (st != RT_OK) return st;
@@ -1265,6 +1269,9 @@ int rt_last_counters(rt_ctx* ctx, rt_counters* out) {
     out->primary_rays = c.primary_rays; out->shadow_rays = c.shadow_rays;
     out->slab_tests = c.slab_tests; out->tri_tests = c.tri_tests;
     out->hit_pixels = c.hit_pixels; out->shadowed_pixels = c.shadowed_pixels;
+    out->skip_checks = c.checks;
+    out->vis_disagreements = c.bad_vis; out->shadow_vis_disagreements = c.bad_shadow_vis;
+    out->entry_disagreements = c.bad_entry; out->cull_disagreements = c.bad_cull; out->instance_disagreements = c.bad_inst;
     return RT_OK;
 }
 

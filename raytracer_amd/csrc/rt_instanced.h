@@ -122,6 +122,26 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
             closest = h.t; who = i; best = h;
         }
     }
+    if (Party::kVerify) {
+        // the reference's loop over the whole list (scene.c:72-108): every entry's own walk, strictly closer wins
+        float ref_closest = 1e30f;
+        int ref_who = -1;
+        uint32_t ref_tri = 0;
+        Work scratch;
+        int unused = 0;
+        for (int k = 0; k < I.n_total; k++) {
+            const MeshArgs& M = I.inst[k];
+            if (M.empty) continue;                    // no triangles: nothing the reference could accept
+            const F3 ld = unit(xform_vector<4>(M.inv, wd));
+            Hit h = no_hit();
+            if (trace_mesh<false, false, true, false, kLeafBatch>(M, nodes, f3(M.cam_o), ld, recip(ld), ref_closest, h, stack, scratch, unused) &&
+                h.t < ref_closest) {
+                ref_closest = h.t; ref_who = k; ref_tri = h.tri;
+            }
+        }
+        work.checks++;
+        if (ref_who != who || (who >= 0 && (f32_as_uint(ref_closest) != f32_as_uint(closest) || ref_tri != best.tri))) work.bad_inst++;
+    }
     out.hit_t = closest;
     if (who < 0) {
         out.r = out.g = out.b = 50; out.shadow = 255; out.inst = -1; out.tri = -1; out.hit = 0; out.dark = 0;
@@ -162,6 +182,21 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
         });
         if (i < 0) break;
         dark = party.template any<COUNT, false>(W, nodes, lo, sd, sinv, stack, work);
+    }
+    if (Party::kVerify) {
+        // the reference's shadow loop (scene.c:124-139): every entry until one blocks
+        bool ref_dark = false;
+        Work scratch;
+        int unused = 0;
+        for (int k = 0; k < I.n_total && !ref_dark; k++) {
+            const MeshArgs& S = I.inst[k];
+            if (S.empty) continue;
+            const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);
+            Hit h = no_hit();
+            ref_dark = trace_mesh<false, false, true, false, kLeafBatch>(S, nodes, lo, f3(S.lit_d), f3(S.lit_inv), 1e30f, h, stack, scratch, unused);
+        }
+        work.checks++;
+        if (ref_dark != dark) work.bad_inst++;
     }
     float diffuse = 0.2f;
     if (!dark) diffuse = fmaxf(diffuse, dot(n, L));

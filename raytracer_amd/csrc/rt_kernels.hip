@@ -65,6 +65,20 @@ struct LaneTotals {
     unsigned long long pixels, hits, darks, slabs, tris;
 };
 
+// What a self-checking launch (RT_FLAG_VERIFY_SKIPS) found, summed over the wave; one atomic per wave and counter.
+__device__ __forceinline__ void flush_checks(DeviceCounters* c, const Work& w) {
+    const unsigned long long checks = wave_sum(w.checks), vis = wave_sum(w.bad_vis), svis = wave_sum(w.bad_shadow_vis);
+    const unsigned long long entry = wave_sum(w.bad_entry), cull = wave_sum(w.bad_cull), inst = wave_sum(w.bad_inst);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&c->checks, checks);
+        if (vis) atomicAdd(&c->bad_vis, vis);
+        if (svis) atomicAdd(&c->bad_shadow_vis, svis);
+        if (entry) atomicAdd(&c->bad_entry, entry);
+        if (cull) atomicAdd(&c->bad_cull, cull);
+        if (inst) atomicAdd(&c->bad_inst, inst);
+    }
+}
+
 __device__ __forceinline__ void flush_counters(DeviceCounters* c, const LaneTotals& t) {
     const unsigned long long prim = wave_sum(t.pixels), hit = wave_sum(t.hits), dark = wave_sum(t.darks);
     const unsigned long long slabs = wave_sum(t.slabs), tris = wave_sum(t.tris);
@@ -81,7 +95,8 @@ __device__ __forceinline__ void flush_counters(DeviceCounters* c, const LaneTota
 // ------------------------------------------------------------------------------------------
 // Variant 0: one thread per pixel, scene read through the vector cache.
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, bool COUNT, bool FULL>
+// VERIFY: the self-checking party walks every ray (SoloVerify, rt_pixel.h); the frame is the one the plain kernel renders.
+template <int BLOCK, bool COUNT, bool FULL, bool VERIFY = false>
 __global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const SceneArgs S, const OutputPlanes O) {
     __shared__ uint32_t lds_stack[kStackDepth * BLOCK];
     LdsStack<BLOCK> stack;
@@ -96,9 +111,11 @@ __global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const 
 
     LaneTotals tot = {0, 0, 0, 0, 0};
     const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
+    Work work;
     if (active) {
-        Work work; work.slabs = 0; work.tris = 0;
-        const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work);
+        PixelOut r;
+        if (VERIFY) r = shade_pixel<COUNT, FULL, false>(A, nodes, SoloVerify(), px, py, stack, work);
+        else r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work);
         store_pixel(O, A.width, px, py, r);
         tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
     }
@@ -106,15 +123,17 @@ __global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const 
         O.tile_clock[2 * (size_t)tile] = t_start;
         O.tile_clock[2 * (size_t)tile + 1] = wall_clock64();
     }
-    if (COUNT) flush_counters(O.counters, tot);
+    if (COUNT || VERIFY) flush_counters(O.counters, tot);
+    if (VERIFY) flush_checks(O.counters, work);
 }
 
 template <int BLOCK>
-static hipError_t launch_direct(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, bool count, bool full, hipStream_t stream) {
+static hipError_t launch_direct(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, bool count, bool full, bool verify, hipStream_t stream) {
     const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
     const int waves_per_block = BLOCK / 64;
     const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
-    if (count && full)  hipLaunchKernelGGL((render_direct<BLOCK, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    if (verify)         hipLaunchKernelGGL((render_direct<BLOCK, false, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
+    else if (count && full)  hipLaunchKernelGGL((render_direct<BLOCK, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     else if (count)     hipLaunchKernelGGL((render_direct<BLOCK, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     else if (full)      hipLaunchKernelGGL((render_direct<BLOCK, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
     else                hipLaunchKernelGGL((render_direct<BLOCK, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, A, S, O);
@@ -127,8 +146,8 @@ static hipError_t launch_direct(const FrameArgs& A, const SceneArgs& S, const Ou
 // ------------------------------------------------------------------------------------------
 // Seven waves per SIMD (71 registers, nothing spilled): 7.9 ms instead of 8.3 at five waves for the 4K / 16-sample / 2-light frame
 // (mean of frames 0 and 45).
-template <int BLOCK, bool COUNT>
-__global__ void __launch_bounds__(BLOCK, 7) render_sampled(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
+template <int BLOCK, bool COUNT, bool VERIFY = false>
+__global__ void __launch_bounds__(BLOCK, VERIFY ? 1 : 7) render_sampled(const FrameArgs A, const SampleArgs X, const SceneArgs S, const OutputPlanes O) {
     extern __shared__ uint32_t lds_stack[];                      // S.stack_entries x BLOCK words
     LdsStack<BLOCK> stack;
     stack.init(&lds_stack[threadIdx.x]);
@@ -138,16 +157,19 @@ __global__ void __launch_bounds__(BLOCK, 7) render_sampled(const FrameArgs A, co
     int px, py;
     tile_pixel(tile, threadIdx.x & 63, tiles_x, px, py);
     LaneTotals tot = {0, 0, 0, 0, 0};
+    Work work;
     if (px < A.width && py < A.height) {
-        Work work; work.slabs = 0; work.tris = 0;
-        const SampledOut r = shade_sampled_pixel<COUNT>(A, X, nodes, Solo(), px, py, stack, work);
+        SampledOut r;
+        if (VERIFY) r = shade_sampled_pixel<COUNT>(A, X, nodes, SoloVerify(), px, py, stack, work);
+        else r = shade_sampled_pixel<COUNT>(A, X, nodes, Solo(), px, py, stack, work);
         const size_t p = (size_t)py * (size_t)A.width + (size_t)px;
         uint8_t* rgb = O.rgb + p * 3;
         rgb[0] = r.r; rgb[1] = r.g; rgb[2] = r.b;
         if (O.hit_id) O.hit_id[p] = r.hit_id;
         tot.pixels = (unsigned long long)X.spp; tot.hits = r.hits; tot.darks = r.darks; tot.slabs = work.slabs; tot.tris = work.tris;
     }
-    if (COUNT) {
+    if (VERIFY) flush_checks(O.counters, work);
+    if (COUNT || VERIFY) {
         // shadow rays = hit samples x lights
         const unsigned long long prim = wave_sum(tot.pixels), hit = wave_sum(tot.hits), dark = wave_sum(tot.darks);
         const unsigned long long slabs = wave_sum(tot.slabs), tris = wave_sum(tot.tris);
@@ -236,11 +258,16 @@ __global__ void __launch_bounds__(64 * kSplitWaves) render_sampled_split(const F
 hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneArgs& S, const OutputPlanes& O, int block, int split, hipStream_t stream) {
     if (A.width <= 0 || A.height <= 0 || X.spp < 1 || X.spp > kMaxSamples || X.n_lights < 1 || X.n_lights > kMaxLights || !O.rgb)
         return hipErrorInvalidValue;
-    const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
-    if (count && !O.counters) return hipErrorInvalidValue;
+    const bool verify = (A.flags & RT_FLAG_VERIFY_SKIPS) != 0;
+    const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0 && !verify;
+    if ((count || verify) && !O.counters) return hipErrorInvalidValue;
     const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
     if (S.stack_entries < 2 || S.stack_entries > (uint32_t)kStackDepth) return hipErrorInvalidValue;
     const size_t stack_bytes = (size_t)S.stack_entries * 64 * sizeof(uint32_t);     // per wave
+    if (verify) {
+        hipLaunchKernelGGL((render_sampled<64, false, true>), dim3(tiles), dim3(64), stack_bytes, stream, A, X, S, O);
+        return hipGetLastError();
+    }
     const size_t dyn = (size_t)X.spp * 192 * sizeof(float) + stack_bytes * kSplitWaves;
     const size_t fixed = 4096;
     // split = 1: when the launch has too few tiles to hide a tile's sample loop behind other tiles (measured at
@@ -266,8 +293,8 @@ hipError_t launch_sampled(const FrameArgs& A, const SampleArgs& X, const SceneAr
 // one for the walk inside an instance's BVH.
 // ------------------------------------------------------------------------------------------
 // Five waves per SIMD (90 registers, nothing spilled): 1.25 against 1.31 ms at four; six and seven waves spill and lose.
-template <int BLOCK, bool COUNT>
-__global__ void __launch_bounds__(BLOCK, 5) render_instanced(const FrameArgs A, const InstancedArgs I, const SceneArgs S, const OutputPlanes O,
+template <int BLOCK, bool COUNT, bool VERIFY = false>
+__global__ void __launch_bounds__(BLOCK, VERIFY ? 1 : 5) render_instanced(const FrameArgs A, const InstancedArgs I, const SceneArgs S, const OutputPlanes O,
                                                           int32_t* __restrict__ hit_tri, const int tlas_entries) {
     // both stacks sized for the trees at hand (entries x BLOCK words each): LDS per wave decides how many
     // waves a CU holds here
@@ -281,9 +308,11 @@ __global__ void __launch_bounds__(BLOCK, 5) render_instanced(const FrameArgs A, 
     int px, py;
     tile_pixel(tile, threadIdx.x & 63, tiles_x, px, py);
     LaneTotals tot = {0, 0, 0, 0, 0};
+    Work work;
     if (px < A.width && py < A.height) {
-        Work work; work.slabs = 0; work.tris = 0;
-        const InstancedOut r = shade_instanced_pixel<COUNT>(A, I, nodes, Solo(), px, py, stack, tstack, work);
+        InstancedOut r;
+        if (VERIFY) r = shade_instanced_pixel<COUNT>(A, I, nodes, SoloVerify(), px, py, stack, tstack, work);
+        else r = shade_instanced_pixel<COUNT>(A, I, nodes, Solo(), px, py, stack, tstack, work);
         const size_t p = (size_t)py * (size_t)A.width + (size_t)px;
         uint8_t* rgb = O.rgb + p * 3;
         rgb[0] = r.r; rgb[1] = r.g; rgb[2] = r.b;
@@ -293,7 +322,8 @@ __global__ void __launch_bounds__(BLOCK, 5) render_instanced(const FrameArgs A, 
         if (O.shadow) O.shadow[p] = r.shadow;
         tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
     }
-    if (COUNT) flush_counters(O.counters, tot);
+    if (COUNT || VERIFY) flush_counters(O.counters, tot);
+    if (VERIFY) flush_checks(O.counters, work);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -382,9 +412,15 @@ hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const Sc
                             int tlas_entries, int block, int wave_tiles, hipStream_t stream) {
     if (A.width <= 0 || A.height <= 0 || !O.rgb || I.n_inst < 0 || (I.n_inst > 0 && !I.inst)) return hipErrorInvalidValue;
     if (tlas_entries < 2 || tlas_entries > kTlasStackDepth || S.stack_entries < 2 || S.stack_entries > (uint32_t)kStackDepth) return hipErrorInvalidValue;
-    const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
-    if (count && !O.counters) return hipErrorInvalidValue;
+    const bool verify = (A.flags & RT_FLAG_VERIFY_SKIPS) != 0;
+    const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0 && !verify;
+    if ((count || verify) && !O.counters) return hipErrorInvalidValue;
     const int tiles = ((A.width + 7) / 8) * ((A.height + 7) / 8);
+    if (verify) {
+        const size_t vlds = (size_t)(tlas_entries + (int)S.stack_entries) * 64 * sizeof(uint32_t);
+        hipLaunchKernelGGL((render_instanced<64, false, true>), dim3(tiles), dim3(64), vlds, stream, A, I, S, O, hit_tri, tlas_entries);
+        return hipGetLastError();
+    }
     if (wave_tiles > 0 && !count) {
         // one stack for both levels: the hierarchy's entries, the end mark, what is left of a leaf of several instances, the
         // mark below an instance's nodes, the instance's entries
@@ -732,6 +768,7 @@ struct CoopGroup {
         return run<true>(M, nodes, o, d, inv, 1e30f, h);
     }
     __device__ __forceinline__ bool exhausted() const { return false; }
+    static constexpr bool kVerify = false;
 };
 
 __device__ __forceinline__ bool in_rect(const int32_t* r, int tx, int ty) { return tx >= r[0] && tx < r[2] && ty >= r[1] && ty < r[3]; }
@@ -1027,9 +1064,11 @@ bool resident_fits(const SceneArgs& S) { return resident_lds_bytes(S) <= kMaxLds
 
 hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, const LaunchConfig& cfg, hipStream_t stream) {
     if (A.width <= 0 || A.height <= 0) return hipErrorInvalidValue;
-    const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0;
-    const bool full = (A.flags & RT_FLAG_REFERENCE_ORDER) != 0;
-    if (count && !O.counters) return hipErrorInvalidValue;
+    const bool verify = (A.flags & RT_FLAG_VERIFY_SKIPS) != 0;
+    const bool count = (A.flags & RT_FLAG_COUNT_WORK) != 0 && !verify;
+    const bool full = (A.flags & RT_FLAG_REFERENCE_ORDER) != 0 && !verify;
+    if ((count || verify) && !O.counters) return hipErrorInvalidValue;
+    if (verify) return A.n_rects != 0 ? hipErrorInvalidValue : launch_direct<64>(A, S, O, false, false, true, stream);   // one lane per ray
     int variant = cfg.variant;
     if ((variant == 1 || variant == 2) && (!cfg.queue || !resident_fits(S))) variant = 0;     // scene too large for LDS
     if (variant != 3 && A.n_rects != 0) return hipErrorInvalidValue;
@@ -1063,9 +1102,9 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
             return launch_tiles<256>(A, S, O, count, full, stream);
         case 0:
         default:
-            if (cfg.block == 64) return launch_direct<64>(A, S, O, count, full, stream);
-            if (cfg.block == 128) return launch_direct<128>(A, S, O, count, full, stream);
-            return launch_direct<256>(A, S, O, count, full, stream);
+            if (cfg.block == 64) return launch_direct<64>(A, S, O, count, full, false, stream);
+            if (cfg.block == 128) return launch_direct<128>(A, S, O, count, full, false, stream);
+            return launch_direct<256>(A, S, O, count, full, false, stream);
     }
 }
 

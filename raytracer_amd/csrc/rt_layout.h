@@ -157,15 +157,18 @@ struct SampleArgs {
 // to be tested against -- the test itself is the reference's, in the instance's own space.
 constexpr int kTlasStackDepth = 32;
 struct InstancedArgs {
-    const MeshArgs* inst;        // n_inst records
-    int32_t n_inst;
+    const MeshArgs* inst;        // one record per entry of the scene's mesh list (n_total), list order
+    int32_t n_inst;              // entries that have triangles (the hierarchy's leaves)
     uint32_t tlas_root;          // leaf ref or index of the root PairNode in `tlas`
     const PairNode* tlas;
     float root_min[3], root_max[3];
+    int32_t n_total;             // entries of the list
 };
 
 struct DeviceCounters {          // accumulated with atomics when counting is requested
     unsigned long long primary_rays, shadow_rays, slab_tests, tri_tests, hit_pixels, shadowed_pixels;
+    // self-checking launches (RT_FLAG_VERIFY_SKIPS): see Work in rt_pixel.h
+    unsigned long long checks, bad_vis, bad_shadow_vis, bad_entry, bad_cull, bad_inst;
 };
 
 // Scene-wide device data (valid for every frame until the meshes change).

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <string>
 #include <future>
+#include <system_error>
 #include <vector>
 
 #include "../../include/rt_mi355.h"
@@ -357,6 +358,11 @@ private:
             }
         }
         size_t n_left = count / 2;
+        // A run of lopsided splits could take the tree past the depth the traversal stack covers (and this recursion past its
+        // own stack): from the point where only halving still fits below the limit, halve.
+        int halvings = 0;
+        while (((size_t)1 << halvings) < count) halvings++;
+        if (depth + halvings >= RT_MAX_TREE_DEPTH) best_axis = -1;
         if (best_axis >= 0) {
             const int a = best_axis;
             const float extent = chi[a] - clo[a];
@@ -375,9 +381,15 @@ private:
         const uint32_t rbase = base + (uint32_t)n_left;                  // the left subtree takes base + 1 .. base + n_left - 1
         if (count >= kRegroupParallelMin && depth < 5) {
             int deep_left = 0;
-            auto left = std::async(std::launch::async, [&]() { return regroup_range(fast, base + 1, first, n_left, depth + 1, deep_left, p.lmin, p.lmax); });
+            std::future<uint32_t> left;
+            bool threaded = true;
+            try {
+                left = std::async(std::launch::async, [&]() { return regroup_range(fast, base + 1, first, n_left, depth + 1, deep_left, p.lmin, p.lmax); });
+            } catch (const std::system_error&) {                         // no thread to be had: this one does both halves
+                threaded = false;
+            }
             r = regroup_range(fast, rbase, first + n_left, count - n_left, depth + 1, deepest, p.rmin, p.rmax);
-            l = left.get();
+            l = threaded ? left.get() : regroup_range(fast, base + 1, first, n_left, depth + 1, deep_left, p.lmin, p.lmax);
             if (deep_left > deepest) deepest = deep_left;
         } else {
             l = regroup_range(fast, base + 1, first, n_left, depth + 1, deepest, p.lmin, p.lmax);
@@ -728,6 +740,11 @@ inline void mesh_shadow_rect(const rt_transform& tf, const float* bmin, const fl
     double mag = placement_magnitude(tf, bmin, bmax, A);
     for (int i = 0; i < 3; i++) mag += (fabs(scene_lo[i]) > fabs(scene_hi[i]) ? fabs(scene_lo[i]) : fabs(scene_hi[i]));
     const double slack = mag * (1.0 / 262144.0) + 0.002;
+    // The kernels normalise the light direction in mesh space in float (ray.c:22).  A caller's own, unnormalised light whose
+    // length squared leaves the float range comes out of that as zeros or NaNs, and the reference's root test then accepts by
+    // the origin alone (0 * inf): no direction to sweep along.  Such lights get the whole frame.
+    const double len2 = (double)A.light_dir[0] * A.light_dir[0] + (double)A.light_dir[1] * A.light_dir[1] + (double)A.light_dir[2] * A.light_dir[2];
+    if (!(len2 > 1e-30 && len2 < 1e30)) return;
     double s_max = 1e300;
     for (int i = 0; i < 3; i++) {
         const double L = A.light_dir[i];

@@ -35,7 +35,15 @@ struct Hit {
 RT_HD Hit no_hit() { Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; h.prio = 0; return h; }
 
 struct Work {
-    uint32_t slabs, tris;
+    uint32_t slabs = 0, tris = 0;
+    // Filled by the self-checking party only (SoloVerify): shortcut decisions that were examined again the reference's way,
+    // and how many of them the reference's way contradicts, by kind.
+    uint32_t checks = 0;
+    uint32_t bad_vis = 0;        // a camera ray passes the root box of a mesh that its tile's screen rectangle leaves out
+    uint32_t bad_shadow_vis = 0; // the same for a shadow ray and the shadow rectangle
+    uint32_t bad_entry = 0;      // a walk entered through a flat mesh's grid ends differently from the walk from the tree's root
+    uint32_t bad_cull = 0;       // the ordered, distance-culled walk (second tree included) ends differently from the reference's own
+    uint32_t bad_inst = 0;       // the walk over the instance hierarchy ends differently from the reference's loop over all instances
 };
 
 // Reads through the pointers a MeshArgs carries (triangles, attributes, texels, grid cells).  Device code reads such a
@@ -263,6 +271,13 @@ RT_HD float uint_as_f32(uint32_t u) {
     float f; memcpy(&f, &u, 4); return f;
 #endif
 }
+RT_HD uint32_t f32_as_uint(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u; memcpy(&u, &f, 4); return u;
+#endif
+}
 RT_HD float comp(F3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
 // Where a ray starts its walk in a flat mesh (MeshArgs::grid, built by Packer::build_grid): the node stored for the cell
@@ -290,9 +305,10 @@ RT_HD uint32_t grid_entry(const MeshArgs& M, F3 o, F3 d, F3 inv, uint32_t root) 
 // any-hit query at the first accepted triangle; the result is the same.
 // BUDGET=true counts the nodes taken off the stack against `steps`; when it runs out the query is
 // abandoned (returns false with steps < 0) and the caller hands the pixel to the cooperative pass.
+// use_grid=false starts a flat mesh's walk at the tree's root as well (the self-checking party compares the two).
 template <bool ANY, bool COUNT, bool FULL, bool BUDGET, uint32_t LB, class Stack, class Nodes>
 RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& hit, Stack& stack, Work& work,
-                      int& steps) {
+                      int& steps, const bool use_grid = true) {
     constexpr bool CULL = !FULL && !ANY;
     Query q;
     if (!begin_query<ANY, COUNT, FULL>(M, o, inv, bound, q, work)) return false;
@@ -304,7 +320,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
         // nothing but triangle tests, so the lanes of a wave do not drag each other through both
         // kinds of work on every step.
         uint32_t ref = entry_ref<false>(M, d);
-        if (M.grid_axis < 3u && ref == M.root_ref && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ref = grid_entry(M, o, d, inv, ref);
+        if (use_grid && M.grid_axis < 3u && ref == M.root_ref && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ref = grid_entry(M, o, d, inv, ref);
         if (!(ref & kLeafBit) && (ref & kGridListBit)) {
             // the cell names its leaves: each one's own box test (the reference reaches a leaf exactly when that passes,
             // the boxes above contain it), nothing else
@@ -412,8 +428,56 @@ struct SoloT {
         return trace_mesh<true, COUNT, FULL, false, LB>(M, nodes, o, d, inv, 1e30f, h, st, w, unused);
     }
     RT_HD bool exhausted() const { return false; }
+    static constexpr bool kVerify = false;
 };
 using Solo = SoloT<kLeafBatch>;
+
+// What a query's caller can see of its result: whether it found a hit below `bound` (scene.c:82 discards the others), and
+// which.  Two walks agree when this is the same.
+RT_HD bool same_outcome(bool a_found, const Hit& a, bool b_found, const Hit& b, float bound) {
+    const bool ea = a_found && a.t < bound, eb = b_found && b.t < bound;
+    if (ea != eb) return false;
+    if (!ea) return true;
+    return f32_as_uint(a.t) == f32_as_uint(b.t) && a.tri == b.tri;
+}
+
+// The self-checking party (RT_FLAG_VERIFY_SKIPS): one lane per ray like Solo, but every query is walked three ways -- as the
+// kernels walk it (second tree, grid entry of flat meshes, nearer child first, distance culling, any-hit stops at the first
+// blocker), the same from the tree's root without the grid, and the reference's own way (its tree, every box whose
+// ancestors' boxes pass, no culling: bvh.c:80-129) -- and the outcomes are compared.  The result handed back is the first
+// one, so a frame rendered with this party is the frame the kernels render; what the reference's way would have changed is
+// counted in Work.
+struct SoloVerify {
+    template <bool COUNT, bool FULL, class Stack, class Nodes>
+    RT_HD bool closest(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, float bound, Hit& h, Stack& st, Work& w) const {
+        int unused = 0;
+        Work scratch;
+        Hit h2 = no_hit(), h3 = no_hit();
+        const bool f1 = trace_mesh<false, COUNT, false, false, kLeafBatch>(M, nodes, o, d, inv, bound, h, st, w, unused);
+        const bool f2 = trace_mesh<false, false, false, false, kLeafBatch>(M, nodes, o, d, inv, bound, h2, st, scratch, unused, false);
+        const bool f3 = trace_mesh<false, false, true, false, kLeafBatch>(M, nodes, o, d, inv, bound, h3, st, scratch, unused);
+        w.checks += 2;
+        if (!same_outcome(f1, h, f2, h2, bound)) w.bad_entry++;
+        if (!same_outcome(f2, h2, f3, h3, bound)) w.bad_cull++;
+        return f1;
+    }
+    template <bool COUNT, bool FULL, class Stack, class Nodes>
+    RT_HD bool any(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv, Stack& st, Work& w) const {
+        int unused = 0;
+        Work scratch;
+        Hit h = no_hit();
+        const bool f1 = trace_mesh<true, COUNT, false, false, kLeafBatch>(M, nodes, o, d, inv, 1e30f, h, st, w, unused);
+        const bool f2 = trace_mesh<true, false, false, false, kLeafBatch>(M, nodes, o, d, inv, 1e30f, h, st, scratch, unused, false);
+        // the reference's shadow pass is its closest-hit walk with only the flag used (scene.c:133-138)
+        const bool f3 = trace_mesh<false, false, true, false, kLeafBatch>(M, nodes, o, d, inv, 1e30f, h, st, scratch, unused);
+        w.checks += 2;
+        if (f1 != f2) w.bad_entry++;
+        if (f2 != f3) w.bad_cull++;
+        return f1;
+    }
+    RT_HD bool exhausted() const { return false; }
+    static constexpr bool kVerify = true;
+};
 
 // One lane alone, but only for as long as the pixel stays cheap: all queries of the pixel draw on
 // one budget of node visits.
@@ -429,6 +493,7 @@ struct SoloBudget {
         return trace_mesh<true, COUNT, FULL, true, kLeafBatch>(M, nodes, o, d, inv, 1e30f, h, st, w, steps);
     }
     RT_HD bool exhausted() const { return steps < 0; }
+    static constexpr bool kVerify = false;
 };
 
 struct PixelOut {
@@ -466,7 +531,15 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     for (int m = 0; m < A.n_mesh; m++) {
         const MeshArgs& M = A.mesh[m];
         // outside A.vis[m] the root test below fails for certain; counting and reference-order runs make it anyway
-        if (!COUNT && !FULL && (tile_x < A.vis[m][0] || tile_x >= A.vis[m][2] || tile_y < A.vis[m][1] || tile_y >= A.vis[m][3])) continue;
+        if (!COUNT && !FULL && (tile_x < A.vis[m][0] || tile_x >= A.vis[m][2] || tile_y < A.vis[m][1] || tile_y >= A.vis[m][3])) {
+            if (Party::kVerify) {                                      // the reference's root test on this ray (scene.c:79, bvh.c:82)
+                const F3 vd = unit(xform_vector<4>(M.inv, wd));
+                float entry;
+                work.checks++;
+                if (slab_t(f3(M.cam_o), recip(vd), M.root_min, M.root_max, entry)) work.bad_vis++;
+            }
+            continue;
+        }
         const F3 lo = f3(M.cam_o);                                     // ray.c:19 (same for every pixel)
         const F3 ld = unit(xform_vector<4>(M.inv, wd));                // ray.c:20,22
         Hit h = no_hit();
@@ -508,7 +581,15 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     for (int m = 0; m < A.n_mesh && !dark; m++) {
         const MeshArgs& S = A.mesh[m];
         // outside A.vis_shadow[m] no surface point seen in this tile can send its shadow ray through the mesh's root box
-        if (!COUNT && !FULL && (tile_x < A.vis_shadow[m][0] || tile_x >= A.vis_shadow[m][2] || tile_y < A.vis_shadow[m][1] || tile_y >= A.vis_shadow[m][3])) continue;
+        if (!COUNT && !FULL && (tile_x < A.vis_shadow[m][0] || tile_x >= A.vis_shadow[m][2] || tile_y < A.vis_shadow[m][1] || tile_y >= A.vis_shadow[m][3])) {
+            if (Party::kVerify) {                                      // the reference's root test on this shadow ray (scene.c:131, bvh.c:82)
+                const F3 vo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);
+                float entry;
+                work.checks++;
+                if (slab_t(vo, f3(S.lit_inv), S.root_min, S.root_max, entry)) work.bad_shadow_vis++;
+            }
+            continue;
+        }
         const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);   // ray.c:19
         dark = party.template any<COUNT, FULL>(S, nodes, lo, f3(S.lit_d), f3(S.lit_inv), stack, work);
         if (DEFER && party.exhausted()) { out.deferred = 1; return out; }

@@ -66,7 +66,15 @@ RT_HD F3 sample_value(const FrameArgs& A, const SampleArgs& X, const Nodes& node
         const MeshArgs& M = A.mesh[m];
         // outside A.vis[m] (two pixels wider than the mesh's root box can reach: a sample stays inside its pixel) the root
         // test fails for certain
-        if (!COUNT && (tile_x < A.vis[m][0] || tile_x >= A.vis[m][2] || tile_y < A.vis[m][1] || tile_y >= A.vis[m][3])) continue;
+        if (!COUNT && (tile_x < A.vis[m][0] || tile_x >= A.vis[m][2] || tile_y < A.vis[m][1] || tile_y >= A.vis[m][3])) {
+            if (Party::kVerify) {                                      // the reference's root test on this ray (scene.c:79, bvh.c:82)
+                const F3 vd = unit(xform_vector<4>(M.inv, wd));
+                float entry;
+                work.checks++;
+                if (slab_t(f3(M.cam_o), recip(vd), M.root_min, M.root_max, entry)) work.bad_vis++;
+            }
+            continue;
+        }
         const F3 ld = unit(xform_vector<4>(M.inv, wd));
         Hit h = no_hit();
         if (party.template closest<COUNT, false>(M, nodes, f3(M.cam_o), ld, recip(ld), closest, h, stack, work) && h.t < closest) {

@@ -320,6 +320,133 @@ def rebuilds(a):
                       "rt_render_frame, rt_render_frames, rt_render_frame_instanced", "pixels": pixels, "pixels_with_a_hit": hits, "identical": True, "wild": a.wild}))
 
 
+def verify_skips(a):
+    """No oracle in the loop: the kernels check their own shortcuts (RT_FLAG_VERIFY_SKIPS).  Random scenes of three kinds -- the
+    reference's meshes under random placements, cameras and lights (frame sizes up to 1280x720); one to four random soups, flat
+    sheets among them (grid entries); lists of 1..40 placed meshes through rt_render_frame_instanced -- are rendered with the
+    flag; every disagreement counter has to stay zero and the planes have to equal the same frame rendered without the flag."""
+    import torch
+    from oracle import pyoracle as po                # only for the meshes and for building BVHs of random soups
+    from raytracer_amd import capi
+    po.lib()
+    meshes = po.default_meshes()
+    ctx = capi.Context(0)
+    for m in meshes:
+        ctx.upload_mesh(m.tris, m.nodes, m.rgba)
+    rng = np.random.default_rng(a.seed)
+    special = [0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e30, -1e30, 1e-30, 1e-42, 1e-7, -1e-7, 1.0, 90.0, 180.0, 360.0]
+    kinds = ("vis_disagreements", "shadow_vis_disagreements", "entry_disagreements", "cull_disagreements", "instance_disagreements")
+    sizes = [(160, 90), (333, 211), (640, 360), (97, 61), (1280, 720), (256, 8)]
+    tex = rng.integers(0, 256, size=(8, 8, 4), dtype=np.uint8)
+    pixels = checks = 0
+    per_kind = {"plain": 0, "soups": 0, "lists": 0}
+
+    def wild(values):
+        return tuple(float(rng.choice(special)) if rng.uniform() < a.wild else float(v) for v in values)
+
+    def view(spread):
+        eye = rng.uniform(-1.2 * spread - 2, 1.2 * spread + 2, 3)
+        at = rng.uniform(-spread, spread, 3)
+        if np.linalg.norm(eye - at) < 1e-3:
+            at = eye + np.array([0.3, -0.2, 0.9])
+        up = (0, 1, 0) if rng.uniform() < 0.8 else tuple(rng.normal(size=3))
+        cam = capi.Camera(capi.Vec3(*wild(eye)), capi.Vec3(*wild(at)), capi.Vec3(*wild(up)), wild([rng.uniform(15, 120)])[0])
+        if a.wild > 0 and rng.uniform() < 0.5:
+            light = capi.Light(capi.Vec3(*wild(rng.normal(size=3))), capi.Vec3(*wild(rng.uniform(-0.5, 2.0, 3))))
+        else:
+            l = po.lib().orc_make_light(po.vec3(*rng.normal(size=3)), po.vec3(*rng.uniform(0.3, 1.6, 3)))
+            light = capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
+        return cam, light
+
+    def describe(cam, light, tfs):
+        return {"camera": [repr(v) for v in (cam.position.x, cam.position.y, cam.position.z, cam.look_at.x, cam.look_at.y, cam.look_at.z,
+                                             cam.up.x, cam.up.y, cam.up.z, cam.fov)],
+                "light": [repr(v) for v in (light.direction.x, light.direction.y, light.direction.z, light.color.x, light.color.y, light.color.z)],
+                "placements": [[repr(v) for v in (t.position.x, t.position.y, t.position.z, t.rotation.x, t.rotation.y, t.rotation.z)] for t in tfs]}
+
+    def checked_plain(c, cam, light, tfs, w, h, what, k):
+        nonlocal pixels, checks
+        a_ = c.render_host(cam, light, tfs, w, h, flags=capi.RT_FLAG_VERIFY_SKIPS)
+        cnt = c.last_counters()
+        b_ = c.render_host(cam, light, tfs, w, h)
+        same = all(np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y) for x, y in zip(a_, b_))
+        bad = {n: cnt[n] for n in kinds if cnt[n]}
+        if bad or not same:
+            print(json.dumps({"scene": k, "seed": a.seed, "kind": what, "size": [w, h], "disagreements": bad, "planes_equal": same, **describe(cam, light, tfs)}))
+            sys.exit(1)
+        pixels += w * h
+        checks += cnt["skip_checks"]
+
+    for k in range(a.scenes):
+        kind = k % 4
+        if kind in (0, 1):
+            spread = float(rng.choice([0.5, 1.5, 5.0, 50.0]))
+            tfs = []
+            for m in range(3):
+                rot = rng.uniform(-3.2, 3.2, 3) if (m < 2 or rng.uniform() < 0.3) else rng.uniform(-0.05, 0.05, 3)
+                tfs.append(capi.Transform(capi.Vec3(*wild(rng.uniform(-spread, spread, 3))), capi.Vec3(*wild(rot))))
+            cam, light = view(spread)
+            w, h = sizes[(k // 2) % len(sizes)]
+            checked_plain(ctx, cam, light, tfs, w, h, "plain", k)
+            per_kind["plain"] += 1
+        elif kind == 2:
+            m = int(rng.integers(1, 5))
+            with capi.Context(0) as c:
+                tfs = []
+                for _ in range(m):
+                    flat = rng.uniform() < 0.5
+                    n = int(rng.choice([40, 200, 800])) if flat else int(rng.choice([1, 5, 64, 300]))
+                    soup = (rng.normal(size=(n, 24)) * rng.choice([0.3, 1.0, 3.0])).astype(np.float32)
+                    if flat:
+                        axis = int(rng.integers(3))
+                        soup[:, [axis, 3 + axis, 6 + axis]] = np.float32(rng.normal() * 0.3)
+                        soup[:, :9] *= np.float32(rng.choice([1.0, 4.0]))
+                        soup[:, [axis, 3 + axis, 6 + axis]] = soup[0, axis]
+                    t, nd = po.build_bvh(soup)
+                    c.upload_mesh(t, nd, tex)
+                    tfs.append(capi.Transform(capi.Vec3(*wild(rng.uniform(-1.5, 1.5, 3))), capi.Vec3(*wild(rng.uniform(-3.2, 3.2, 3)))))
+                cam, light = view(2.0)
+                checked_plain(c, cam, light, tfs, 200, 120, "soups", k)
+            per_kind["soups"] += 1
+        else:
+            n = int(rng.integers(1, 41))
+            spread = float(rng.choice([1.0, 3.0, 8.0]))
+            ids = [int(rng.choice([0, 1, 1, 1, 2])) for _ in range(n)]
+            tfs = [capi.Transform(capi.Vec3(*wild(rng.uniform(-spread, spread, 3))), capi.Vec3(*wild(rng.uniform(-3.2, 3.2, 3)))) for _ in range(n)]
+            if n > 3 and rng.uniform() < 0.3:
+                tfs[n - 1] = tfs[0]; ids[n - 1] = ids[0]
+            cam, light = view(spread)
+            w, h = [(160, 90), (97, 61), (200, 40)][(k // 4) % 3]
+            lst = capi.Context.make_instances(ids, tfs)
+            planes = []
+            for flags in (capi.RT_FLAG_VERIFY_SKIPS, 0):
+                rgb = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+                hi = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+                htri = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+                t = torch.empty((h, w), dtype=torch.int32, device="cuda:0")      # the bits of the distance
+                sh = torch.empty((h, w), dtype=torch.uint8, device="cuda:0")
+                ctx.render_instanced(cam, light, lst, w, h, rgb, hit_instance=hi, hit_tri=htri, hit_t=t, shadow=sh, flags=flags)
+                if flags:
+                    cnt = ctx.last_counters()
+                ctx.sync()
+                planes.append((rgb, hi, htri, t, sh))
+            same = all(torch.equal(x, y) for x, y in zip(*planes))
+            bad = {nm: cnt[nm] for nm in kinds if cnt[nm]}
+            if bad or not same:
+                print(json.dumps({"scene": k, "seed": a.seed, "kind": "lists", "size": [w, h], "ids": ids, "disagreements": bad, "planes_equal": same,
+                                  **describe(cam, light, tfs)}))
+                sys.exit(1)
+            pixels += w * h
+            checks += cnt["skip_checks"]
+            per_kind["lists"] += 1
+        if (k + 1) % 100 == 0:
+            print(f"[soak] {k + 1} scenes checked themselves: no disagreement", file=sys.stderr, flush=True)
+    print(json.dumps({"scenes": a.scenes, "seed": a.seed, "mode": "RT_FLAG_VERIFY_SKIPS: shortcuts against the reference's way, on the device, ray by ray",
+                      "scenes_by_kind": per_kind, "pixels": pixels, "decisions_examined": checks, "disagreements": 0,
+                      "planes_equal_to_the_unflagged_frame": True, "wild": a.wild}))
+    ctx.close()
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--scenes", type=int, default=500)
@@ -336,7 +463,11 @@ def main():
     p.add_argument("--rebuilds", action="store_true", help="one context whose second mesh gets a new random soup every step (rebuild / replace routes)")
     p.add_argument("--multi", action="store_true", help="scenes of one to six random soups through the plain, batched and instanced frame paths")
     p.add_argument("--soups", action="store_true", help="random triangle soups with special values among their numbers, both builders and packers")
+    p.add_argument("--verify-skips", action="store_true",
+                   help="the kernels check their own shortcuts (RT_FLAG_VERIFY_SKIPS) on random plain scenes, random soups and instance lists; no oracle in the loop")
     a = p.parse_args()
+    if a.verify_skips:
+        return verify_skips(a)
     if a.instanced:
         return instanced(a)
     if a.soups:

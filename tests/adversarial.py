@@ -168,6 +168,8 @@ def degenerate_views(po):
     yield "light from below", tf, cam, raw_light((0, -1, 0))
     yield "light direction not normalised", tf, cam, raw_light((3, 4, -2))
     yield "NaN light direction", tf, cam, raw_light((nan, 1, 0))
+    yield "light direction of 1e30 (its normalisation in mesh space overflows: shadow rays without a direction)", tf, cam, raw_light((-1e30, 0.2, -0.85))
+    yield "light direction of 1e-25 (its square leaves the float range downwards)", tf, cam, raw_light((1e-25, 2e-25, -1e-25))
     yield "negative light colour", tf, cam, raw_light(light.direction.tup(), (-1.0, 0.5, 300.0))
     yield "drone with a NaN angle", moved(0, rot=(0, nan, 0)), cam, light
     yield "treasure infinitely far away", moved(1, pos=(inf, 0, 0)), cam, light

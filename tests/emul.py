@@ -30,7 +30,9 @@ class Light(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("primary_rays", "shadow_rays", "slab_tests", "tri_tests", "hit_pixels", "shadowed_pixels")]
+                ("primary_rays", "shadow_rays", "slab_tests", "tri_tests", "hit_pixels", "shadowed_pixels", "skip_checks",
+                 "vis_disagreements", "shadow_vis_disagreements", "entry_disagreements", "cull_disagreements",
+                 "instance_disagreements")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -62,9 +64,9 @@ def lib():
         L.emul_sample_offset.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_float)] * 2
         L.emul_sample_offset.restype = None
         L.emul_render_sampled.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), i32, C.POINTER(Transform), i32, i32, C.c_uint32,
-                                          i32, i32, vp, vp, C.POINTER(Counters)]
+                                          i32, i32, vp, vp, C.POINTER(Counters), i32]
         L.emul_render_instanced.argtypes = [vp, C.POINTER(Camera), C.POINTER(Light), vp, vp, i32, i32, i32, vp, vp, vp, vp, vp,
-                                            C.POINTER(Counters), C.POINTER(i32), C.POINTER(i32)]
+                                            C.POINTER(Counters), C.POINTER(i32), C.POINTER(i32), i32]
         L.emul_upscale.argtypes = [vp, i32, i32, i32, i32, i32, vp]
         L.emul_upscale.restype = None
         L.emul_set_regroup.argtypes = [vp, i32]
@@ -75,6 +77,10 @@ def lib():
         L.emul_regroup_routes_agree.argtypes = [vp, i32, vp, i32]
         L.emul_work_plane.argtypes = [vp, vp]
         L.emul_work_plane.restype = None
+        L.emul_set_vis_shrink.argtypes = [vp, i32]
+        L.emul_set_vis_shrink.restype = None
+        L.emul_damage_grid.argtypes = [vp, i32]
+        L.emul_damage_second_tree.argtypes = [vp, i32]
         _lib = L
     return _lib
 
@@ -155,7 +161,7 @@ class Scene:
         assert lib().emul_mesh_prios(self.h, mesh, out.ctypes.data) == 0
         return out
 
-    def render(self, cam, light, tfs, w, h, full=False, per_pixel=False, screen_cull=False):
+    def render(self, cam, light, tfs, w, h, full=False, per_pixel=False, screen_cull=False, verify=False):
         arr = (Transform * max(len(tfs), 1))(*[conv(t, Transform) for t in tfs])
         rgb = np.zeros((h, w, 3), np.uint8)
         hid = np.zeros((h, w), np.int32)
@@ -166,13 +172,13 @@ class Scene:
         pt = np.zeros((h, w), np.uint32) if per_pixel else None
         cam2, light2 = conv(cam, Camera), conv(light, Light)
         st = lib().emul_render(self.h, C.byref(cam2), C.byref(light2), arr, len(tfs), w, h, rgb.ctypes.data,
-                               hid.ctypes.data, ht.ctypes.data, sh.ctypes.data, C.byref(cnt), 2 if screen_cull else (1 if full else 0),
+                               hid.ctypes.data, ht.ctypes.data, sh.ctypes.data, C.byref(cnt), 3 if verify else (2 if screen_cull else (1 if full else 0)),
                                ps.ctypes.data if per_pixel else None, pt.ctypes.data if per_pixel else None)
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_id": hid, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(), "px_slabs": ps,
                 "px_tris": pt, "stack_high": lib().emul_stack_high(self.h)}
 
-    def render_sampled(self, cam, lights, tfs, spp, seed, w, h):
+    def render_sampled(self, cam, lights, tfs, spp, seed, w, h, verify=False):
         arr = (Transform * max(len(tfs), 1))(*[conv(t, Transform) for t in tfs])
         larr = (Light * len(lights))(*[conv(l, Light) for l in lights])
         rgb = np.zeros((h, w, 3), np.uint8)
@@ -180,11 +186,11 @@ class Scene:
         cnt = Counters()
         cam2 = conv(cam, Camera)
         st = lib().emul_render_sampled(self.h, C.byref(cam2), larr, len(lights), arr, len(tfs), spp, seed, w, h,
-                                       rgb.ctypes.data, hid.ctypes.data, C.byref(cnt))
+                                       rgb.ctypes.data, hid.ctypes.data, C.byref(cnt), 1 if verify else 0)
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_id": hid, "counters": cnt.as_dict()}
 
-    def render_instanced(self, cam, light, mesh_ids, tfs, w, h):
+    def render_instanced(self, cam, light, mesh_ids, tfs, w, h, verify=False):
         ids = np.ascontiguousarray(mesh_ids, np.int32)
         arr = (Transform * max(len(tfs), 1))(*[conv(t, Transform) for t in tfs])
         rgb = np.zeros((h, w, 3), np.uint8)
@@ -197,10 +203,20 @@ class Scene:
         cam2, light2 = conv(cam, Camera), conv(light, Light)
         st = lib().emul_render_instanced(self.h, C.byref(cam2), C.byref(light2), ids.ctypes.data, arr, len(tfs), w, h,
                                          rgb.ctypes.data, inst.ctypes.data, tri.ctypes.data, ht.ctypes.data, sh.ctypes.data,
-                                         C.byref(cnt), C.byref(pairs), C.byref(depth))
+                                         C.byref(cnt), C.byref(pairs), C.byref(depth), 1 if verify else 0)
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_inst": inst, "hit_tri": tri, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(),
                 "tlas_pairs": pairs.value, "tlas_depth": depth.value}
+
+    # deliberate damage, for the tests that the self-checking party (verify=True) notices wrong shortcuts
+    def set_vis_shrink(self, tiles: int):
+        lib().emul_set_vis_shrink(self.h, int(tiles))
+
+    def damage_grid(self, mesh: int) -> int:
+        return lib().emul_damage_grid(self.h, int(mesh))
+
+    def damage_second_tree(self, mesh: int) -> int:
+        return lib().emul_damage_second_tree(self.h, int(mesh))
 
     def record_work(self, plane):
         """plane: uint32 array [h, w, 2] that instanced frames fill with each pixel's {box tests, triangle tests}; None stops it.

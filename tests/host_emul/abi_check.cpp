@@ -107,6 +107,15 @@ int main() {
         expect(k.primary_rays == px && k.hit_pixels == hits, "counters");
         expect(back(d_rgb, px * 3) == ref, "counting frame is the same frame");
     }
+    {   // the kernels check their own shortcuts: same frame, nothing contradicted
+        check(rt_render_frame(c, &cam, &lights[0], tf, 3, W, H, RT_FLAG_VERIFY_SKIPS, d_rgb, nullptr, nullptr, nullptr, nullptr), "rt_render_frame self-check");
+        rt_counters k;
+        check(rt_last_counters(c, &k), "rt_last_counters");
+        expect(k.primary_rays == px && k.hit_pixels == hits && k.skip_checks >= px, "self-check examined every query");
+        expect(k.vis_disagreements + k.shadow_vis_disagreements + k.entry_disagreements + k.cull_disagreements + k.instance_disagreements == 0,
+               "no shortcut contradicted by the reference's way");
+        expect(back(d_rgb, px * 3) == ref, "self-checking frame is the same frame");
+    }
     for (int n : {1, 5, 16}) {
         std::vector<rt_transform> many((size_t)n * 3);
         for (int f = 0; f < n; f++) for (int m = 0; m < 3; m++) many[(size_t)f * 3 + m] = tf[m];

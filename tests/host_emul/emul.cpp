@@ -42,8 +42,18 @@ struct EmulScene {
     bool keep_hierarchy = false;       // instanced frames: the product's hierarchy kept from call to call
     float box_allowance = 0.0f;        // what the world boxes were widened by last time
     uint32_t* work_plane = nullptr;    // instanced frames: per pixel {box tests, triangle tests} of both rays, when set
+    int vis_shrink = 0;                // tests of the self-check: screen and shadow rectangles made this many tiles too small on every side
     StandingTlas standing;
     int hierarchy_reused = 0;          // calls that reused the kept tree
+};
+struct CheckTotals {
+    unsigned long long checks = 0, vis = 0, shadow_vis = 0, entry = 0, cull = 0, inst = 0;
+    void add(const Work& w) { checks += w.checks; vis += w.bad_vis; shadow_vis += w.bad_shadow_vis; entry += w.bad_entry; cull += w.bad_cull; inst += w.bad_inst; }
+    void merge(const CheckTotals& o) { checks += o.checks; vis += o.vis; shadow_vis += o.shadow_vis; entry += o.entry; cull += o.cull; inst += o.inst; }
+    void store(rt_counters* c) const {
+        c->skip_checks = checks; c->vis_disagreements = vis; c->shadow_vis_disagreements = shadow_vis;
+        c->entry_disagreements = entry; c->cull_disagreements = cull; c->instance_disagreements = inst;
+    }
 };
 }  // namespace
 
@@ -55,6 +65,32 @@ const char* emul_last_error(void* s) { return ((EmulScene*)s)->err.c_str(); }
 int emul_stack_high(void* s) { return ((EmulScene*)s)->stack_high; }
 void emul_keep_hierarchy(void* s, int on) { ((EmulScene*)s)->keep_hierarchy = on != 0; ((EmulScene*)s)->standing.clear(); ((EmulScene*)s)->hierarchy_reused = 0; }
 int emul_hierarchy_reused(void* s) { return ((EmulScene*)s)->hierarchy_reused; }
+// Deliberate damage, for the tests that the self-checking party notices a wrong shortcut:
+// rectangles too small; a flat mesh's grid whose every cell names the first leaf only; the second tree's root with its left box moved out of every ray's way.
+void emul_set_vis_shrink(void* s, int tiles) { ((EmulScene*)s)->vis_shrink = tiles; }
+int emul_damage_grid(void* sp, int mesh) {
+    EmulScene* s = (EmulScene*)sp;
+    if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;
+    PackedMesh& pk = s->meshes[(size_t)mesh].pk;
+    if (pk.grid_axis >= 3 || pk.grid.empty()) return RT_ERR_UNSUPPORTED;
+    uint32_t leaf = 0;
+    for (const PairNode& n : pk.pairs) { if (n.lref & kLeafBit) { leaf = n.lref; break; } if (n.rref & kLeafBit) { leaf = n.rref; break; } }
+    if (!leaf) return RT_ERR_UNSUPPORTED;
+    const size_t cells = (size_t)pk.grid_n * (size_t)pk.grid_n;
+    for (size_t i = 0; i < cells && i < pk.grid.size(); i++) pk.grid[i] = leaf;
+    return RT_OK;
+}
+int emul_damage_second_tree(void* sp, int mesh) {
+    EmulScene* s = (EmulScene*)sp;
+    if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;
+    const PackedMesh& pk = s->meshes[(size_t)mesh].pk;
+    if (pk.root_ref == pk.ref_root || (pk.root_ref & kLeafBit)) return RT_ERR_UNSUPPORTED;      // no second tree
+    size_t base = 0;
+    for (int m = 0; m < mesh; m++) base += s->meshes[(size_t)m].pk.pairs.size();
+    PairNode& n = s->all_pairs[base + pk.root_ref];
+    for (int c = 0; c < 3; c++) { n.lmin[c] = 1.0e9f; n.lmax[c] = 1.0e9f + 64.0f; }         // a box no ray of the scene meets
+    return RT_OK;
+}
 void emul_set_regroup(void* s, int on) { ((EmulScene*)s)->regroup = on != 0; }   // for meshes added afterwards
 
 // Packs a mesh twice -- with the second tree built by run(), and with only the reference's tree followed by
@@ -164,19 +200,26 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         }
         for (int m = 0; any && m < n_tf; m++) mesh_shadow_rect(tfs[m], A.mesh[m].root_min, A.mesh[m].root_max, slo, shi, A, A.vis_shadow[m]);
     }
+    for (int m = 0; m < n_tf && s->vis_shrink; m++)
+        for (int32_t* r : {A.vis[m], A.vis_shadow[m]}) { r[0] += s->vis_shrink; r[1] += s->vis_shrink; r[2] -= s->vis_shrink; r[3] -= s->vis_shrink; }
     GlobalNodes nodes; nodes.all = s->all_pairs.data();
     unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
     int high = 0;
+    CheckTotals checks;
     #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_slab, c_tri, c_hit, c_dark) reduction(max : high)
     for (int y = 0; y < height; y++) {
+        CheckTotals row;
         for (int x = 0; x < width; x++) {
             ArrayStack st;
-            Work w; w.slabs = 0; w.tris = 0;
+            Work w;
             // full: 1 = reference visiting order; 0 = nearer child first with distance culling; 2 = the same without work
-            // counts, as the kernels run it: meshes are skipped for tiles outside their screen rectangle
+            // counts, as the kernels run it: meshes are skipped for tiles outside their screen rectangle; 3 = as 2 with the
+            // self-checking party (RT_FLAG_VERIFY_SKIPS)
             PixelOut r = full == 1 ? shade_pixel<true, true, false>(A, nodes, Solo(), x, y, st, w)
                        : full == 2 ? shade_pixel<false, false, false>(A, nodes, Solo(), x, y, st, w)
+                       : full == 3 ? shade_pixel<false, false, false>(A, nodes, SoloVerify(), x, y, st, w)
                                    : shade_pixel<true, false, false>(A, nodes, Solo(), x, y, st, w);
+            row.add(w);
             const size_t p = (size_t)y * width + x;
             rgb[p * 3] = r.r; rgb[p * 3 + 1] = r.g; rgb[p * 3 + 2] = r.b;
             if (hit_id) hit_id[p] = r.hit_id;
@@ -187,12 +230,15 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
             c_slab += w.slabs; c_tri += w.tris; c_hit += r.hit; c_dark += r.dark;
             if (st.high > high) high = st.high;
         }
+        #pragma omp critical
+        checks.merge(row);
     }
     s->stack_high = high;
     if (counters) {
         counters->primary_rays = (uint64_t)width * height; counters->shadow_rays = c_hit;
         counters->slab_tests = c_slab; counters->tri_tests = c_tri;
         counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
+        checks.store(counters);
     }
     return RT_OK;
 }
@@ -201,7 +247,8 @@ void emul_sample_offset(uint32_t x, uint32_t y, uint32_t s, uint32_t seed, float
 
 // The product's sampled pixel (rt_sampled.h) over a frame.
 int emul_render_sampled(void* sp, const rt_camera* cam, const rt_light* lights, int32_t n_lights, const rt_transform* tfs, int32_t n_tf,
-                        int32_t spp, uint32_t seed, int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_id, rt_counters* counters) {
+                        int32_t spp, uint32_t seed, int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_id, rt_counters* counters,
+                        int32_t verify) {
     EmulScene* s = (EmulScene*)sp;
     if (n_tf != (int32_t)s->meshes.size() || n_tf > kMaxMeshes || n_lights < 1 || n_lights > kMaxLights) { s->err = "counts"; return RT_ERR_INVALID; }
     FrameArgs A; memset(&A, 0, sizeof A);
@@ -222,22 +269,29 @@ int emul_render_sampled(void* sp, const rt_camera* cam, const rt_light* lights, 
     fill_samples(lights, n_lights, spp, seed, A, X);
     GlobalNodes nodes; nodes.all = s->all_pairs.data();
     unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
+    CheckTotals checks;
     #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_slab, c_tri, c_hit, c_dark)
     for (int y = 0; y < height; y++) {
+        CheckTotals row;
         for (int x = 0; x < width; x++) {
             ArrayStack st;
-            Work w; w.slabs = 0; w.tris = 0;
-            const SampledOut r = shade_sampled_pixel<true>(A, X, nodes, Solo(), x, y, st, w);
+            Work w;
+            const SampledOut r = verify ? shade_sampled_pixel<false>(A, X, nodes, SoloVerify(), x, y, st, w)
+                                        : shade_sampled_pixel<true>(A, X, nodes, Solo(), x, y, st, w);
             const size_t p = (size_t)y * width + x;
             rgb[p * 3] = r.r; rgb[p * 3 + 1] = r.g; rgb[p * 3 + 2] = r.b;
             if (hit_id) hit_id[p] = r.hit_id;
             c_slab += w.slabs; c_tri += w.tris; c_hit += r.hits; c_dark += r.darks;
+            row.add(w);
         }
+        #pragma omp critical
+        checks.merge(row);
     }
     if (counters) {
         counters->primary_rays = (uint64_t)width * height * (uint64_t)spp; counters->shadow_rays = c_hit * (uint64_t)n_lights;
         counters->slab_tests = c_slab; counters->tri_tests = c_tri;
         counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
+        checks.store(counters);
     }
     return RT_OK;
 }
@@ -249,7 +303,7 @@ void emul_work_plane(void* sp, uint32_t* per_pixel) { ((EmulScene*)sp)->work_pla
 // The product's instanced pixel (rt_instanced.h) with the product's instance hierarchy (rt_pack.h).
 int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light, const int32_t* mesh_ids, const rt_transform* tfs, int32_t n_inst,
                           int32_t width, int32_t height, uint8_t* rgb, int32_t* hit_inst, int32_t* hit_tri, float* hit_t, uint8_t* shadow,
-                          rt_counters* counters, int32_t* tlas_pairs, int32_t* tlas_depth) {
+                          rt_counters* counters, int32_t* tlas_pairs, int32_t* tlas_depth, int32_t verify) {
     EmulScene* s = (EmulScene*)sp;
     FrameArgs A; memset(&A, 0, sizeof A);
     fill_camera(*cam, *light, width, height, A);
@@ -281,16 +335,20 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
     InstancedArgs I;
     std::vector<PairNode> direct(T.pairs.size());
     write_direct(T, direct.data());
-    I.inst = inst.data(); I.n_inst = (int32_t)ids.size(); I.tlas_root = direct_ref(T, T.root_ref); I.tlas = direct.data();
+    I.inst = inst.data(); I.n_inst = (int32_t)ids.size(); I.n_total = n_inst; I.tlas_root = direct_ref(T, T.root_ref); I.tlas = direct.data();
     memcpy(I.root_min, T.root_min, 12); memcpy(I.root_max, T.root_max, 12);
     GlobalNodes nodes; nodes.all = s->all_pairs.data();
     unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
+    CheckTotals checks;
     #pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_slab, c_tri, c_hit, c_dark)
     for (int y = 0; y < height; y++) {
+        CheckTotals row;
         for (int x = 0; x < width; x++) {
             ArrayStack st, ts;
-            Work w; w.slabs = 0; w.tris = 0;
-            const InstancedOut r = shade_instanced_pixel<true>(A, I, nodes, Solo(), x, y, st, ts, w);
+            Work w;
+            const InstancedOut r = verify ? shade_instanced_pixel<false>(A, I, nodes, SoloVerify(), x, y, st, ts, w)
+                                          : shade_instanced_pixel<true>(A, I, nodes, Solo(), x, y, st, ts, w);
+            row.add(w);
             const size_t p = (size_t)y * width + x;
             rgb[p * 3] = r.r; rgb[p * 3 + 1] = r.g; rgb[p * 3 + 2] = r.b;
             if (hit_inst) hit_inst[p] = r.inst;
@@ -300,11 +358,14 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
             c_slab += w.slabs; c_tri += w.tris; c_hit += r.hit; c_dark += r.dark;
             if (s->work_plane) { s->work_plane[p * 2] = w.slabs; s->work_plane[p * 2 + 1] = w.tris; }
         }
+        #pragma omp critical
+        checks.merge(row);
     }
     if (counters) {
         counters->primary_rays = (uint64_t)width * height; counters->shadow_rays = c_hit;
         counters->slab_tests = c_slab; counters->tri_tests = c_tri;
         counters->hit_pixels = c_hit; counters->shadowed_pixels = c_dark;
+        checks.store(counters);
     }
     return RT_OK;
 }

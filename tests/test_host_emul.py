@@ -75,7 +75,7 @@ def test_pipeline_equals_oracle_on_golden_frames(po, meshes, em_default, golden_
 def test_reference_order_mode_does_the_reference_work_exactly(po, meshes, em_default, request):
     tfs = po.animation_transforms(45)
     got, want = compare(po, em_default, meshes, tfs, po.default_camera(), po.default_light(), 200, 112, full=True)
-    assert got["counters"] == want.counters
+    assert {k: got["counters"][k] for k in want.counters} == want.counters
     # culled mode: same image, never more work, per pixel
     fast = em_default.render(po.default_camera(), po.default_light(), tfs, 200, 112, full=False, per_pixel=True)
     slow = em_default.render(po.default_camera(), po.default_light(), tfs, 200, 112, full=True, per_pixel=True)
@@ -205,7 +205,7 @@ def test_leaf_larger_than_four_triangles(po, count):
     # the work is the reference's in reference-order mode: one triangle test per triangle of the leaf
     full = s.render(front_camera(po), po.default_light(), [po.Transform(po.vec3(0, 0, 0), po.vec3(0.2, 0.4, 0))], 96, 96, full=True)
     if count <= 127:
-        assert full["counters"] == want.counters
+        assert {k: full["counters"][k] for k in want.counters} == want.counters
     else:       # the chain's own links are extra box tests; the triangle tests are still the reference's
         assert full["counters"]["tri_tests"] == want.counters["tri_tests"]
         assert full["counters"]["slab_tests"] >= want.counters["slab_tests"]
