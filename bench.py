@@ -14,6 +14,10 @@ finished batch of RGB8 framebuffers is gathered to rank 0 (torch.distributed: RC
 --backend nccl) inside the timed region while the next batch renders.  Framebuffers stay in HBM;
 nothing is copied to the host inside the timed region.  Before the W warm-up steps every rank keeps
 its GPU busy with 24 untimed launches, so that the short timed region runs at working clocks.
+The timed region -- exactly K steps between barrier + synchronize on both sides -- lasts a few
+milliseconds, so it is repeated (the same K steps each time, at least five times and until half a
+second has gone by); `value` comes from the median repetition (maximum over ranks per repetition),
+and the spread is reported beside it (`timing`).
 
 With --gpus N > 1 and no WORLD_SIZE in the environment this program starts its own N ranks (a
 child `python -m torch.distributed.run`, before anything in this process has touched a GPU) and
@@ -50,7 +54,10 @@ B_SLAB, B_TRI, B_HIT, B_PIXEL = 32, 36, 64, 3
 F_SLAB, F_TRI, F_XFORM = 22, 50, 45
 FRAME_STRIDE = 7               # step k renders entry (7 k) mod L of the rank's L frames
 SETTLE = 24                    # untimed launches before the warm-up
-PMC_PROFILE = os.path.join(REPO, "profiles", "r2_traffic.json")
+PMC_PROFILE = os.path.join(REPO, "profiles", "r3_traffic.json")
+ISSUE_PROFILE = os.path.join(REPO, "profiles", "r3_valu_issue_summary.json")
+XGMI_LINK_GBS_ONE_WAY = 76.8   # MI355X: seven links of 153.6 GB/s (both directions together) per GPU, one per peer
+MIN_TIMED_SECONDS, MIN_REPEATS, MAX_REPEATS = 0.5, 5, 2000
 
 
 def parse(argv=None):
@@ -77,6 +84,7 @@ def parse(argv=None):
                         "Exercises rank start-up, frame dealing, the gathers and their check; its value is not a measurement")
     p.add_argument("--cpu-frames", type=int, default=48, help="animation frames the CPU baseline renders (an even sample; 48 take 10-12 s on 16 threads)")
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port when this program starts its own ranks (0 = a free one)")
+    p.add_argument("--repeats", type=int, default=0, help="repetitions of the timed region (0: at least five, and until half a second has gone by)")
     return p.parse_args(argv)
 
 
@@ -150,6 +158,60 @@ def cpu_baseline(width, height, n_frames):
                       f"{'compiled reference functions (gcc -O3 -ffp-contract=off) + composition loop' if use_ref else 'CPU restatement'}, "
                       f"OpenMP dynamic rows, {threads} threads, {dt:.1f} s",
             "ms_per_frame": round(dt / n_frames * 1e3, 2)}
+
+
+def gather_budget(width, height, frames_per_s_per_gpu, world, measured):
+    """What the gather of RGB8 framebuffers to rank 0 (scene.c:186-206 consumes them there) asks of the links at this
+    run's per-GPU frame rate.  Every peer has its own xGMI link to rank 0, so the gather is one point-to-point stream
+    per link; rank 0 takes in the sum."""
+    frame = width * height * 3
+    per_peer = frames_per_s_per_gpu * frame / 1e9
+    out = {"gather_bytes_per_step": frame,
+           "per_gpu_frames_per_s": round(frames_per_s_per_gpu, 1),
+           "per_peer_GBs_required": round(per_peer, 2),
+           "xgmi_link_GBs_one_way_assumed": XGMI_LINK_GBS_ONE_WAY,
+           "link_share_required": round(per_peer / XGMI_LINK_GBS_ONE_WAY, 3),
+           "rank0_ingest_GBs_required": {str(n): round(per_peer * (n - 1), 1) for n in (2, 4, 8)},
+           "note": ("the gathers of this run are inside the timed region: `value` already pays for them" if measured else
+                    "projection from a run without peers -- unmeasured on hardware: each peer must push per_peer_GBs_required over its own "
+                    "link to rank 0 (link_share_required of one direction of that link) for N GPUs to render N times this rate; rank 0's "
+                    "HBM takes rank0_ingest_GBs_required in, a few percent of its 8 TB/s")}
+    return out
+
+
+def issue_model(slabs, tris, rays, alg_flops, kernel_seconds):
+    """The reference's arithmetic priced in vector-issue cycles of gfx950 (scripts/valu_issue_bench.hip, measured: a wave64
+    add / subtract / multiply occupies its SIMD for 2.1 cycles, a fused multiply-add 2.4, min / max / compare / select /
+    convert and the two-wide packed forms 4.0-4.1, reciprocal and square root 8.0; 1024 SIMDs).  Per box test (aabb.c:33-56 with
+    the reciprocals hoisted): 6 subtractions, 6 multiplications, 6 min/max and two three-way min/max.  Per triangle test
+    (ray.c:42-67): 36 add/sub/mul, one correctly rounded division (10 instructions), 6 compares.  Per ray and mesh
+    (ray.c:3-23 hoisted to a 3x4 transform, a normalisation): 30 add/sub/mul, a square root, a division.  The floor is the
+    time these instructions alone would take with every lane busy and nothing else issued."""
+    cost = {"add_sub_mul": 2.11, "fma": 2.44, "min_max_cmp_select": 4.03, "rcp_sqrt": 8.03}
+    src = None
+    try:
+        t = json.load(open(ISSUE_PROFILE))["cycles_per_wave_instruction"]
+        cost = {"add_sub_mul": t["v_add_f32"]["all64@8"], "fma": t["v_fma_f32"]["all64@8"],
+                "min_max_cmp_select": t["v_min_f32"]["all64@8"], "rcp_sqrt": t["v_rcp_f32"]["all64@8"]}
+        src = "profiles/" + os.path.basename(ISSUE_PROFILE)
+    except Exception:
+        pass
+    div = cost["rcp_sqrt"] + 4 * cost["fma"] + 5 * cost["min_max_cmp_select"]      # v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup + a select
+    box = 12 * cost["add_sub_mul"] + 8 * cost["min_max_cmp_select"]
+    tri = 36 * cost["add_sub_mul"] + div + 6 * cost["min_max_cmp_select"]
+    xform = 30 * cost["add_sub_mul"] + cost["rcp_sqrt"] + div
+    wave_cycles = (slabs * box + tris * tri + rays * 3 * xform) / 64.0                 # 64 lanes per wave instruction
+    clock_hz, simds = 2.4e9, 1024
+    floor_s = wave_cycles / (simds * clock_hz)
+    return {"cycles_per_wave64_instruction": cost, "source": src,
+            "cycles_per_box_test_wave": round(box, 1), "cycles_per_triangle_test_wave": round(tri, 1), "cycles_per_ray_transform_wave": round(xform, 1),
+            "arithmetic_floor_ms": round(floor_s * 1e3, 4),
+            "ceiling_TFLOPs": round(alg_flops / floor_s / 1e12, 2),
+            "frac_of_ceiling": round(floor_s / kernel_seconds, 4),
+            "basis": "the reference-equivalent tests of the launch priced at the measured issue cost of their own float operations, all 64 lanes "
+                     "busy, no address, stack or control instructions, 2.4 GHz: the time below which no bit-exact vector-ALU kernel can "
+                     "render them; the kernel's ordered, culled traversal runs fewer tests than that count, which is how frac_of_ceiling "
+                     "can approach or pass 1"}
 
 
 class PatternScene:
@@ -279,39 +341,67 @@ def main():
     if grouped:
         dist.barrier()
 
-    # ---- timed region: exactly `steps` frames
+    # ---- timed region: exactly `steps` frames, repeated
     # rank 0 drops the gathered frames (an encoder would consume them here)
-    gather = sharding.FrameGather(rank, world, ring=RING - 1, collective_at_one_rank=grouped) if grouped else None
+    # (a rehearsal checks them instead: every frame of every rank's batches carries the byte its frame number gives it)
+    verified = [0, 0]                                          # frames checked, frames right
+
+    def check_patterns(seq_no, per_rank):
+        b = seq_no % nb
+        for r, t in enumerate(per_rank):
+            sh = sharding.frames_for_rank(NF, r, world) or [r % NF]
+            theirs = frame_sequence(sh, a.steps)[b * a.batch:min((b + 1) * a.batch, a.steps)]
+            for k, f in enumerate(theirs):
+                verified[0] += 1
+                verified[1] += int(bool((t[k] == (37 * f + 11) % 251).all()))
+
+    gather = (sharding.FrameGather(rank, world, ring=RING - 1, consume=check_patterns if rehearse else None, collective_at_one_rank=grouped)
+              if grouped else None)
     if gather is not None:
         gather.prealloc(nb, bufs[0])
-        dist.barrier()
-    device_sync()
-    t0 = time.perf_counter()
-    for b in range(nb):
-        scene.render_frames(batches[b], W, H, bufs[b % len(bufs)], stream=sptr)
+
+    def timed_pass():
+        if grouped:
+            dist.barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        for b in range(nb):
+            scene.render_frames(batches[b], W, H, bufs[b % len(bufs)], stream=sptr)
+            if gather is not None:
+                gather.submit(bufs[b % len(bufs)])
         if gather is not None:
-            gather.submit(bufs[b % len(bufs)])
-    if gather is not None:
-        gather.finish()
-    device_sync()
-    if grouped:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    say(f"timed region done in {dt:.4f} s")
+            gather.finish()
+        device_sync()
+        if grouped:
+            dist.barrier()
+        return time.perf_counter() - t0
+
+    times = [timed_pass()]
+    repeats = a.repeats if a.repeats > 0 else min(MAX_REPEATS, max(MIN_REPEATS, int(MIN_TIMED_SECONDS / max(times[0], 1e-6)) + 1))
+    if rehearse and a.repeats <= 0:
+        repeats = 3
+    if grouped:                                                # every rank runs the same number of repetitions: the largest wish
+        want = torch.tensor([repeats], dtype=torch.int64, device=dev)
+        dist.all_reduce(want, op=dist.ReduceOp.MAX)
+        repeats = int(want.item())
+    while len(times) < repeats:
+        times.append(timed_pass())
+    say(f"timed region: {repeats} repetitions, median {sorted(times)[len(times) // 2]:.4f} s")
 
     rays_rank = sum(info[f]["primary_rays"] + info[f]["shadow_rays"] for f in seq)
     if grouped:
-        stats = torch.tensor([dt, float(rays_rank)], dtype=torch.float64, device=dev)
-        tmax = stats[:1].clone()
+        tmax = torch.tensor(times, dtype=torch.float64, device=dev)      # per repetition: the slowest rank
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        rsum = stats[1:].clone()
+        rsum = torch.tensor([float(rays_rank)], dtype=torch.float64, device=dev)
         dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
-        dt_all, rays_all = float(tmax.item()), float(rsum.item())
+        per_rep, rays_all = [float(x) for x in tmax.tolist()], float(rsum.item())
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, "cpu" if rehearse else f"cuda:{local}")
     else:
-        dt_all, rays_all = dt, float(rays_rank)
+        per_rep, rays_all = list(times), float(rays_rank)
         rank_devices = ["cpu" if rehearse else f"cuda:{local}"]
+    ordered = sorted(per_rep)
+    dt_all = ordered[len(ordered) // 2]                              # the median repetition
 
     # ---- untimed: what arrives on rank 0 is what the ranks rendered.  Every rank sends the first batch of its
     # timed steps once more; rank 0 renders the same frames itself and compares the bytes.
@@ -351,25 +441,27 @@ def main():
             ms.append(ctx.last_kernel_ms())
             alg_bytes.append(sum(work(info[f])[0] for f in fr)); alg_flops.append(sum(work(info[f])[1] for f in fr))
             own_bytes.append(sum(work(own[f])[0] for f in fr)); own_flops.append(sum(work(own[f])[1] for f in fr))
+        # full-size launches only (the last launch of the region may hold fewer frames)
+        full = [i for i, fr in enumerate(batches) if len(fr) == a.batch] or list(range(len(batches)))
+        ms, alg_bytes, alg_flops = [ms[i] for i in full], [alg_bytes[i] for i in full], [alg_flops[i] for i in full]
+        own_bytes, own_flops = [own_bytes[i] for i in full], [own_flops[i] for i in full]
+        launch_frames = float(np.mean([len(batches[i]) for i in full]))
         kern_ms = float(np.mean(ms))
         secs = kern_ms * 1e-3
         tfl = float(np.mean(alg_flops)) / secs / 1e12
         roof = {"bound": "valu", "achieved": round(tfl, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tfl / VALU_PEAK_TFLOPS, 5), "traffic": None, "hbm_frac": None,
-                # the same work against what this instruction stream can issue at most: one rounding per reference operation
-                # means no fused multiply-adds (x1/2) and, but for the slab test, no two-wide packing (x1/2)
-                "unfused_unpacked_peak": round(VALU_PEAK_TFLOPS / 4, 1),
-                # against that ceiling the work the kernel itself executes is what counts (its ordered, culled traversal runs fewer
-                # tests than the reference-equivalent figure above, which can therefore exceed the ceiling)
-                "frac_of_unfused_unpacked_peak": round(float(np.mean(own_flops)) / secs / 1e12 / (VALU_PEAK_TFLOPS / 4), 4),
-                "kernel": "render_batch (block %d), %d frames per launch" % (ctx.get_option("block"), a.batch),
+                "kernel": "render_batch (block %d), %d frames per launch (the %d full-size launches of the region)" % (ctx.get_option("block"), a.batch, len(full)),
                 "kernel_ms": round(kern_ms, 4), "algorithmic_flops_per_launch": int(np.mean(alg_flops)),
                 "basis": "FLOPs of the reference-equivalent traversal (every box and triangle test scene.c/bvh.c would run: 22 per box "
-                         "test, 50 per triangle test, 45 per ray and mesh) over the kernel's mean HIP-event duration; the peak assumes "
-                         "packed FMAs on every lane, the bit-exact build issues neither (one rounding per reference operation)",
+                         "test, 50 per triangle test, 45 per ray and mesh) over the kernel's mean HIP-event duration; the peak is a fused "
+                         "multiply-add on every lane every two cycles, the bit-exact build has one rounding per reference operation (no FMA) "
+                         "and most of its operations (min, max, compare, select) issue at half that rate: see issue_model",
                 "algorithmic_bytes_per_launch": int(np.mean(alg_bytes)),
                 "cache_served_GBs": round(float(np.mean(alg_bytes)) / secs / 1e9, 1),
                 "kernel_counted": {"flops_per_launch": int(np.mean(own_flops)), "bytes_per_launch": int(np.mean(own_bytes)),
+                                   "box_tests_per_launch": int(np.mean([sum(own[f]["slab_tests"] for f in batches[i]) for i in full])),
+                                   "triangle_tests_per_launch": int(np.mean([sum(own[f]["tri_tests"] for f in batches[i]) for i in full])),
                                    "TFLOP/s": round(float(np.mean(own_flops)) / secs / 1e12, 3),
                                    "basis": "tests the ordered, distance-culled traversal of the kernel executes"},
                 "note": "the scene (150 KB of nodes, 170 KB of triangles) is cache resident: the algorithmic bytes are served by "
@@ -391,20 +483,24 @@ def main():
             scene.render(f, W, H, bufs[0][0], stream=sptr)
             one.append(ctx.last_kernel_ms())
         single_ms = round(float(np.mean(one)), 4)
+        roof["issue_model"] = issue_model(float(np.mean([sum(info[f]["slab_tests"] for f in batches[i]) for i in full])),
+                                          float(np.mean([sum(info[f]["tri_tests"] for f in batches[i]) for i in full])),
+                                          float(np.mean([sum(info[f]["primary_rays"] + info[f]["shadow_rays"] for f in batches[i]) for i in full])),
+                                          float(np.mean(alg_flops)), secs)
         if os.path.exists(PMC_PROFILE):
             try:        # counters of a separate rocprofv3 --pmc pass over this same command (scripts/gpu_pmc.sh), per launch
                 pmc = json.load(open(PMC_PROFILE))
                 hbm = pmc.get("hbm_bytes_per_launch")
                 if hbm:
-                    # per frame from the counter pass, times the mean number of frames in this run's launches
-                    hbm = int(hbm / float(pmc.get("frames_per_launch", 8)) * float(np.mean([len(fr) for fr in batches])))
+                    # per frame from the counter pass, times the number of frames in this run's full-size launches
+                    hbm = int(hbm / float(pmc.get("frames_per_launch", 8)) * launch_frames)
                 roof["traffic"] = hbm
                 if hbm:
                     roof["hbm_frac"] = round(hbm / secs / 1e9 / HBM_PEAK_GBS, 5)
-                roof["traffic_source"] = ("profiles/%s: FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per %s launch (scaled to this run's mean "
-                                          "of %.1f frames per launch), separate --pmc pass, not the timed launches"
-                                          % (os.path.basename(PMC_PROFILE), pmc.get("kernel"), float(np.mean([len(fr) for fr in batches]))))
-                roof["valu_issue_utilisation_pmc"] = pmc.get("valu_issue_utilisation")
+                roof["traffic_source"] = ("profiles/%s: FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per %s launch (scaled to %.0f frames per "
+                                          "launch), a separate --pmc pass of the builder's over this command's launches, not this run's"
+                                          % (os.path.basename(PMC_PROFILE), pmc.get("kernel"), launch_frames))
+                roof["valu_busy_estimate_pmc"] = pmc.get("valu_busy_estimate")    # [low, high]: per-class instruction counts x measured issue costs
                 roof["valu_lane_utilisation_pmc"] = pmc.get("valu_lane_utilisation")
                 roof["vector_memory_path_busy_pmc"] = pmc.get("ta_busy")          # TA_TA_BUSY over the 256 CUs: the next limit after issue
             except Exception:
@@ -434,6 +530,11 @@ def main():
                        "backend": (dist.get_backend() if grouped else None),
                        "rank_devices": rank_devices,
                        "gathered_frames_equal_rank0_render": gather_ok},
+            "timing": {"repeats": len(per_rep), "value_from": "median repetition (each: exactly `steps` frames between barrier + synchronize, slowest rank)",
+                       "timed_seconds_total": round(sum(per_rep), 4),
+                       "ms_per_step_min_median_max": [round(ordered[0] / a.steps * 1e3, 4), round(dt_all / a.steps * 1e3, 4), round(ordered[-1] / a.steps * 1e3, 4)],
+                       "value_min_max": [round(rays_all / ordered[-1] / 1e6, 2), round(rays_all / ordered[0] / 1e6, 2)]},
+            "gather_budget": gather_budget(W, H, a.steps / dt_all, world, grouped and world > 1),
             "frames_per_s": round(a.steps * world / dt_all, 2),
             "rays_per_frame": int(rays_rank / a.steps),
             "single_frame_kernel_ms": single_ms,
@@ -443,6 +544,8 @@ def main():
         }
         if rehearse:
             out["rehearsal"] = "cpu: no GPU, no rendering, frames are byte patterns -- value is not a measurement"
+            out["config"]["rehearsal_frames_checked_on_rank0"] = verified[0]
+            out["config"]["rehearsal_frames_right"] = verified[1]
             out["data"] = "byte patterns"
         print(json.dumps(out), flush=True)
     scene.close()

@@ -34,6 +34,9 @@ def parse(argv):
     p.add_argument("--backend", default="nccl")
     p.add_argument("--one-device", action="store_true", help="rehearsal: every rank on GPU 0 (with --backend gloo)")
     p.add_argument("--master-port", type=int, default=0)
+    p.add_argument("--rehearse-cpu", action="store_true",
+                   help="no GPU and no rendering: frames are byte patterns in host memory, gathered over gloo and checked frame by frame "
+                        "on rank 0 -- the ranks, the frame dealing, the padding and the gathers of an N-GPU run, on a machine without GPUs")
     p.add_argument("--collective-at-one-rank", action="store_true",
                    help="started under torch.distributed.run with one rank: create the process group and gather through it all the same")
     return p.parse_args(argv)
@@ -50,19 +53,34 @@ def main():
     from raytracer_amd import animation, demo, sharding
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    rehearse = a.rehearse_cpu
+    if rehearse:
+        a.backend = "gloo"
+    elif not torch.cuda.is_available():
         sys.exit("animation_job.py: no GPU visible; the rendering core has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if rehearse:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     grouped = world > 1 or (a.collective_at_one_rank and "WORLD_SIZE" in os.environ)
     if grouped:
         dist.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
-    scene = demo.DemoScene(local)
-    ctx = scene.ctx
-    ctx.set_option("timing", 0)
     W, H, NF = a.width, a.height, demo.N_FRAMES
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)                      # kernels, gathers and the upscale are ordered by this stream
+    if rehearse:
+        import bench
+        scene, ctx = bench.PatternScene(), None
+    else:
+        scene = demo.DemoScene(local)
+        ctx = scene.ctx
+        ctx.set_option("timing", 0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)                  # kernels, gathers and the upscale are ordered by this stream
+    sptr = None if rehearse else stream.cuda_stream
+
+    def device_sync():
+        if not rehearse:
+            torch.cuda.synchronize(dev)
     mine = sharding.frames_for_rank(NF, rank, world)
     longest = (NF + world - 1) // world
     B = a.batch if a.batch > 0 else max(1, min(16, (longest + 1) // 2))
@@ -79,14 +97,19 @@ def main():
     hashing = rank == 0 and (a.hash or gold is not None)      # a host-side pass over every frame: only where it checks something
     sha = hashlib.sha256()
     seen = [0]
+    pattern_ok = [0]
     sink = None
-    if rank == 0 and a.out:
+    if rank == 0 and a.out and not rehearse:
         sink = animation.AnimationSink(ctx, a.out, W, H, a.scale, NF, 4000)
 
     def consume(_seq, per_rank):
         frames = torch.stack([t.to(dev) for t in per_rank], dim=1).reshape(-1, H, W, 3)       # frame = (batch * B + i) * world + r
         n = min(int(frames.shape[0]), NF - seen[0])
         if n > 0:
+            if rehearse:                               # frame f carries the byte PatternScene gives it: every pixel of every frame, in order
+                for i in range(n):
+                    f = seen[0] + i
+                    pattern_ok[0] += int(bool((frames[i] == (37 * f + 11) % 251).all()))
             if hashing:
                 sha.update(frames[:n].cpu().numpy().tobytes())
             if sink is not None:
@@ -94,8 +117,8 @@ def main():
             seen[0] += n
 
     # one untimed launch: code objects and clocks
-    scene.render_frames([mine[0] if mine else 0], W, H, bufs[0][:1], stream=stream.cuda_stream)
-    torch.cuda.synchronize(dev)
+    scene.render_frames([mine[0] if mine else 0], W, H, bufs[0][:1], stream=sptr)
+    device_sync()
     if grouped:
         dist.barrier()
     gather = sharding.FrameGather(rank, world, ring=3, consume=consume, collective_at_one_rank=grouped)
@@ -104,10 +127,10 @@ def main():
     for b in range(n_batches):
         buf = bufs[b % len(bufs)]
         frames = [mine[b * B + k] if b * B + k < len(mine) else (mine[-1] if mine else 0) for k in range(B)]    # padding: dropped by rank 0
-        scene.render_frames(frames, W, H, buf, stream=stream.cuda_stream)
+        scene.render_frames(frames, W, H, buf, stream=sptr)
         gather.submit(buf)
     gather.finish()
-    torch.cuda.synchronize(dev)
+    device_sync()
     t_frames = time.perf_counter() - t0
     if sink is not None:
         sink.close()
@@ -121,7 +144,9 @@ def main():
                           "seconds_until_file_closed": round(t_all, 4) if sink is not None else None,
                           "frames_per_s": round(seen[0] / t_frames, 1), "all_frames_sha256": sha.hexdigest() if hashing else None,
                           "equals_compiled_reference": (sha.hexdigest() == gold) if gold else None,
-                          "file": a.out or None}), flush=True)
+                          "file": a.out or None,
+                          **({"rehearsal": "cpu: byte patterns over gloo, no GPU -- not a measurement", "frames_verified_in_order": pattern_ok[0]}
+                             if rehearse else {})}), flush=True)
     scene.close()
     if grouped:
         dist.destroy_process_group()

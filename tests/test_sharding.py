@@ -258,6 +258,40 @@ def test_bench_starts_its_own_ranks_when_given_a_gpu_count():
     assert "rehearsal" in out and out["steps"] == 8 and out["scaling"] == "weak"
 
 
+def test_bench_eight_ranks_as_the_first_multi_gpu_command_will_run():
+    """`python bench.py --gpus 8 --steps 20 --warmup 5` at the bench's own frame size, rehearsed on byte patterns over gloo: eight
+    ranks report, every rank deals itself 12 frames (batches of 8 + 8 + 4 per repetition, a ring of three gathers in flight), and
+    rank 0 checks every pixel of every frame of every gathered batch against the byte its frame number gives it."""
+    import json
+    r = _run_bench("--gpus", "8", "--rehearse-cpu", "--steps", "20", "--warmup", "5", timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["config"]["world_size"] == 8 and out["config"]["rank_devices"] == ["cpu"] * 8
+    assert out["config"]["frames_per_launch"] == 8 and out["config"]["gathered_frames_equal_rank0_render"] is True
+    reps = out["timing"]["repeats"]
+    assert reps >= 3 and out["config"]["rehearsal_frames_checked_on_rank0"] == 8 * 20 * reps
+    assert out["config"]["rehearsal_frames_right"] == out["config"]["rehearsal_frames_checked_on_rank0"]
+    assert out["gather_budget"]["gather_bytes_per_step"] == 1920 * 1080 * 3
+    lo, med, hi = out["timing"]["ms_per_step_min_median_max"]
+    assert lo <= med <= hi and abs(out["ms_per_step"] - med) < 1e-3
+
+
+def test_animation_job_over_eight_ranks_delivers_every_frame_in_order():
+    """scripts/animation_job.py --gpus 8 (the reference driver's 96 frames, frame f on rank f mod 8, two gather messages of six
+    frames per rank, the last one padded), rehearsed on byte patterns over gloo: rank 0 ends up with frames 0..95 in order."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "animation_job.py"), "--gpus", "8", "--rehearse-cpu", "--width", "720", "--height", "540"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["backend"] == "gloo" and out["frames"] == 96 and out["frames_verified_in_order"] == 96
+    assert out["frames_per_launch"] == 6
+
+
 def test_bench_single_rank_can_go_through_the_process_group():
     """One rank under torch.distributed.run with --collective-at-one-rank: the process group exists and every batch is gathered
     through it (here gloo on byte patterns; on a GPU machine the same switch runs RCCL's gather with one GPU)."""
