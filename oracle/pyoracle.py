@@ -136,6 +136,10 @@ def lib():
         L.orc_render_frame_sampled.restype = None
         L.orc_render_frame_sampled.argtypes = [C.POINTER(Mesh), C.c_int32, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.c_int32,
                                                C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int32]
+        L.orc_render_window_sampled.restype = None
+        L.orc_render_window_sampled.argtypes = [C.POINTER(Mesh), C.c_int32, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.c_int32,
+                                                C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int32]
         L.orc_animation_transforms.restype = None
         L.orc_animation_transforms.argtypes = [C.c_int32, C.POINTER(Transform)]
         L.orc_max_threads.restype = C.c_int
@@ -331,6 +335,19 @@ def render_frame_sampled(meshes: Sequence[HostMesh], transforms: Sequence[Transf
     cnt = Counters()
     lib().orc_render_frame_sampled(arr, len(meshes), C.byref(cam), larr, len(lights), spp, seed, width, height,
                                    _ptr(rgb), _ptr(hid), C.byref(cnt), threads)
+    return Frame(rgb, hid, None, None, cnt.as_dict())
+
+
+def render_window_sampled(meshes: Sequence[HostMesh], transforms: Sequence[Transform], cam: Camera, lights: Sequence[Light],
+                          spp: int, seed: int, width: int, height: int, x0: int, y0: int, win_w: int, win_h: int, threads: int = 0) -> Frame:
+    """The pixels [x0, x0 + win_w) x [y0, y0 + win_h) of render_frame_sampled's width x height frame, as planes of the window's size."""
+    arr = (Mesh * len(meshes))(*[m.as_struct(tf) for m, tf in zip(meshes, transforms)])
+    larr = (Light * len(lights))(*lights)
+    rgb = np.zeros((win_h, win_w, 3), np.uint8)
+    hid = np.zeros((win_h, win_w), np.int32)
+    cnt = Counters()
+    lib().orc_render_window_sampled(arr, len(meshes), C.byref(cam), larr, len(lights), spp, seed, width, height, x0, y0, win_w, win_h,
+                                    _ptr(rgb), _ptr(hid), C.byref(cnt), threads)
     return Frame(rgb, hid, None, None, cnt.as_dict())
 
 

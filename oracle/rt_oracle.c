@@ -501,6 +501,17 @@ void orc_sample_offset(uint32_t x, uint32_t y, uint32_t s, uint32_t seed, float*
 void orc_render_frame_sampled(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* lights,
                               int32_t n_lights, int32_t spp, uint32_t seed, int32_t width, int32_t height,
                               uint8_t* rgb, int32_t* hit_id, OCounters* counters, int32_t threads) {
+    orc_render_window_sampled(meshes, mesh_count, cam, lights, n_lights, spp, seed, width, height, 0, 0, width, height,
+                              rgb, hit_id, counters, threads);
+}
+
+/* The pixels [x0, x0 + win_w) x [y0, y0 + win_h) of the same frame (rays are those of the width x height frame), written
+ * row-major into planes of the window's own size: a frame of 8 million pixels and 16 samples is hours of CPU work, a window
+ * of it is seconds. */
+void orc_render_window_sampled(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* lights,
+                               int32_t n_lights, int32_t spp, uint32_t seed, int32_t width, int32_t height,
+                               int32_t x0, int32_t y0, int32_t win_w, int32_t win_h,
+                               uint8_t* rgb, int32_t* hit_id, OCounters* counters, int32_t threads) {
     float aspect = (float)width / height;
     uint64_t c_prim = 0, c_shad = 0, c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
 #ifdef _OPENMP
@@ -508,8 +519,8 @@ void orc_render_frame_sampled(const OMesh* meshes, int32_t mesh_count, const OCa
 #endif
     #pragma omp parallel for schedule(dynamic, 4) num_threads(threads) \
         reduction(+ : c_prim, c_shad, c_slab, c_tri, c_hit, c_dark)
-    for (int y = 0; y < height; y++) {
-        for (int x = 0; x < width; x++) {
+    for (int y = y0; y < y0 + win_h; y++) {
+        for (int x = x0; x < x0 + win_w; x++) {
             Work w = {0, 0};
             float acc[3] = {0, 0, 0};
             int first_id = -1;
@@ -569,7 +580,7 @@ void orc_render_frame_sampled(const OMesh* meshes, int32_t mesh_count, const OCa
                 }
                 for (int k = 0; k < 3; k++) acc[k] = s == 0 ? value[k] : acc[k] + value[k];
             }
-            size_t px = (size_t)y * width + x;
+            size_t px = (size_t)(y - y0) * win_w + (x - x0);
             for (int k = 0; k < 3; k++) {
                 float v = spp > 1 ? acc[k] / (float)spp : acc[k];
                 rgb[px * 3 + k] = (unsigned char)v;

@@ -120,6 +120,10 @@ void   orc_sample_offset(uint32_t x, uint32_t y, uint32_t s, uint32_t seed, floa
 void   orc_render_frame_sampled(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* lights,
                                 int32_t n_lights, int32_t spp, uint32_t seed, int32_t width, int32_t height,
                                 uint8_t* rgb, int32_t* hit_id, OCounters* counters, int32_t threads);
+void   orc_render_window_sampled(const OMesh* meshes, int32_t mesh_count, const OCamera* cam, const OLight* lights,
+                                 int32_t n_lights, int32_t spp, uint32_t seed, int32_t width, int32_t height,
+                                 int32_t x0, int32_t y0, int32_t win_w, int32_t win_h,
+                                 uint8_t* rgb, int32_t* hit_id, OCounters* counters, int32_t threads);
 int    orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -51,9 +51,11 @@ def main():
     p.add_argument("--reps", type=int, default=5)
     p.add_argument("--host-build", action="store_true")
     p.add_argument("--no-regroup", action="store_true", help="host build: keep only the reference's tree (option regroup = 0)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--profile", action="store_true", help="no work-counting launches: the program a profiler is pointed at")
     a = p.parse_args()
     from raytracer_amd import capi, demo, host_api
+    import side_roofline
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     scene = demo.DemoScene(0)                                    # for the camera, the light, the animation and the assets
@@ -93,11 +95,30 @@ def main():
         rays = c["primary_rays"] + c["shadow_rays"]
         rows.append({"frame": f, "kernel_ms": round(t, 3), "rays": rays, "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1),
                      "box_tests_per_ray": round(c["slab_tests"] / rays, 1), "triangle_tests_per_ray": round(c["tri_tests"] / rays, 1)})
+        if not a.profile:
+            rows[-1]["roofline"] = side_roofline.roofline("render_tiles (rt_render_frame's default kernel), ten-million-triangle mesh", c, rays * 3, t, "r3_pmc_flat.json")
+    cpu = None
+    if not a.profile and not a.no_cpu_baseline:
+        # the reference's loop over a smaller scene of the same kind (13 x 13 copies, 533 k triangles): its own build of that soup
+        from oracle import pyoracle as po
+        po.lib()
+        om = po.default_meshes()
+        small = baked_grid(treasure, 13, a.spacing, 3)
+        bt, bn = po.build_bvh(small)
+        meshes3 = [om[0], po.HostMesh(bt, bn, om[1].rgba), om[2]]
+        f0 = int(a.frames.split(",")[0])
+        otf = [po.animation_transforms(f0)[0], po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0)), po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))]
+
+        def run():
+            fr = po.render_frame(meshes3, otf, po.default_camera(), po.default_light(), 480, 270)
+            return fr.counters["primary_rays"] + fr.counters["shadow_rays"], po.lib().orc_max_threads()
+        cpu = side_roofline.cpu_baseline(run, "13 x 13 copies baked into one mesh of 533 195 triangles (the full scene's build alone is minutes of CPU), 480x270, "
+                                              "the reference's un-culled walk (bvh.c:80-129), OpenMP dynamic rows")
     out = {"metric": "Mrays/s (primary+shadow), stress scene as one mesh", "unit": "Mrays/s",
            "value": round(float(np.mean([r["Mrays_per_s"] for r in rows])), 1),
            "config": {"workload": f"{W}x{H}, {a.side}x{a.side} treasures baked into one mesh of {n_tris} triangles + ground + drone"},
            "dtype": "f32", "bake_s": round(t_bake, 2), "build_pack_upload_s": round(t_build, 3), "bvh_build": "host" if a.host_build else "device",
-           "build_stats": stats, "frames": rows}
+           "build_stats": stats, "frames": rows, "roofline": rows[0].get("roofline"), "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     ctx.close()
     scene.close()

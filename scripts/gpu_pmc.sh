@@ -1,7 +1,7 @@
 #!/bin/bash
 # Hardware-counter passes over scripts/prof_frames.py, one rocprofv3 run per pass (counters are
 # not split over passes automatically; a pass holds at most 8 SQ, 4 TCC, 4 TCP, 2 TA, 2 GRBM).
-# usage: gpu_pmc.sh <tag> [prof_frames.py args...]
+# usage: gpu_pmc.sh <tag> [prof_frames.py args...]        (PROG=scripts/other.py in the environment: another program, same passes)
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
@@ -10,7 +10,7 @@ OUT=gpurun_out/pmc_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 run_pass() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- python3 scripts/prof_frames.py $ARGS > "$OUT/$name.log" 2>&1
+  timeout -s KILL ${PASS_TIMEOUT:-120} rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- python3 ${PROG:-scripts/prof_frames.py} $ARGS > "$OUT/$name.log" 2>&1
   rc=$?
   echo "pass $name rc=$rc"
   return $rc

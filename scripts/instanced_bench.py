@@ -27,9 +27,11 @@ def main():
     p.add_argument("--frames", default="0,45")
     p.add_argument("--reps", type=int, default=5)
     p.add_argument("--wave", type=int, default=-1, help="option instanced_wave: tiles per wave of the per-wavefront scheduler, 0 = nested loops per lane")
+    p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-rebuild", action="store_true", help="move the drone by its transform only (no per-frame BVH rebuild)")
     a = p.parse_args()
     from raytracer_amd import capi, demo
+    import side_roofline
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     scene = demo.DemoScene(0)
@@ -89,13 +91,27 @@ def main():
         t = float(np.median(ms))
         rays = c["primary_rays"] + c["shadow_rays"]
         rows.append({"frame": f, "kernel_ms": round(t, 3), "call_ms_with_host_rebuild": round(float(np.median(wall)), 3),
-                     "rays": rays, "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1)})
+                     "rays": rays, "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1),
+                     # ray transforms are not counted by the kernel: two proposed instances per ray is what the hierarchy gives on this scene
+                     "roofline": side_roofline.roofline("render_instanced (block 64)", c, rays * 2, t, "r3_pmc_instanced.json")})
+    cpu = None
+    if not a.no_cpu_baseline:
+        from oracle import pyoracle as po
+        po.lib()
+        om = po.default_meshes()
+        otf = [po.Transform(po.vec3(t.position.x, t.position.y, t.position.z), po.vec3(t.rotation.x, t.rotation.y, t.rotation.z)) for t in tfs[1:]]
+        otf.insert(0, po.animation_transforms(int(a.frames.split(",")[0]))[0])           # the drone placed by its transform
+
+        def run():
+            fr, _, _ = po.render_frame_ids([om[i] for i in ids], otf, po.default_camera(), po.default_light(), 48, 27)
+            return fr.counters["primary_rays"] + fr.counters["shadow_rays"], po.lib().orc_max_threads()
+        cpu = side_roofline.cpu_baseline(run, f"the same {len(ids)}-entry list at 48x27 through the reference's loop over the whole list (scene.c:72-108), OpenMP dynamic rows")
     out = {"metric": "Mrays/s (primary+shadow), instanced scene", "unit": "Mrays/s",
            "value": round(float(np.mean([r["Mrays_per_s"] for r in rows])), 1),
            "config": {"workload": f"{W}x{H}, {len(ids)} instances ({placed} placed triangles): {a.side}x{a.side} treasures + ground + drone, "
                                   "hierarchy over the instances rebuilt on the host per frame"
                                   + ("" if a.no_rebuild else "; the drone's vertices rewritten, its BVH rebuilt and re-uploaded per frame")},
-           "dtype": "f32", "instanced_wave": ctx.get_option("instanced_wave"), "frames": rows}
+           "dtype": "f32", "instanced_wave": ctx.get_option("instanced_wave"), "frames": rows, "roofline": rows[0]["roofline"], "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     scene.close()
 

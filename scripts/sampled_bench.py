@@ -25,9 +25,11 @@ def main():
     p.add_argument("--frames", default="0,45")
     p.add_argument("--reps", type=int, default=3)
     p.add_argument("--shares", default="2,4,8", help="also render the frame as N interleaved strip shares (what N GPUs would each do)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--split", type=int, default=-1, help="context option sampled_split: 0 looped, 1 by tile count (default), 2 always four waves per tile")
     a = p.parse_args()
     from raytracer_amd import capi, demo, host_api as H
+    import side_roofline
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     scene = demo.DemoScene(0)
@@ -56,7 +58,8 @@ def main():
         t = float(np.median(ms))
         rays = c["primary_rays"] + c["shadow_rays"]
         row = {"frame": f, "ms": round(t, 3), "primary_rays": c["primary_rays"], "shadow_rays": c["shadow_rays"],
-               "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1)}
+               "Mrays_per_s": round(rays / (t * 1e-3) / 1e6, 1),
+               "roofline": side_roofline.roofline("render_sampled (block 64), one frame per launch", c, rays * 3, t, "r3_pmc_sampled.json")}
         # one GPU renders every share in turn: the slowest share is the frame time of N GPUs before the gather
         for n in [int(x) for x in a.shares.split(",") if x]:
             per = []
@@ -70,10 +73,22 @@ def main():
             row[f"shares_{n}"] = {"slowest_ms": round(max(per), 3), "fastest_ms": round(min(per), 3),
                                   "speedup_before_gather": round(t / max(per), 2)}
         rows.append(row)
+    cpu = None
+    if not a.no_cpu_baseline:
+        from oracle import pyoracle as po
+        po.lib()
+        om = po.default_meshes()
+        ols = [po.lib().orc_make_light(po.vec3(*d), po.vec3(*c)) for d, c in list(zip(dirs, cols))[:a.lights]]
+        f0 = int(a.frames.split(",")[0])
+
+        def run():
+            fr = po.render_window_sampled(om, po.animation_transforms(f0), po.default_camera(), ols, a.spp, 0, W, Hh, W // 2 - 128, Hh // 2 - 128, 256, 256)
+            return fr.counters["primary_rays"] + fr.counters["shadow_rays"], po.lib().orc_max_threads()
+        cpu = side_roofline.cpu_baseline(run, f"a 256x256 window at the centre of frame {f0} ({a.spp} samples, {a.lights} lights), OpenMP dynamic rows")
     out = {"metric": "Mrays/s (primary+shadow), sampled frame", "unit": "Mrays/s",
            "value": round(float(np.mean([r["Mrays_per_s"] for r in rows])), 1),
            "config": {"workload": f"{W}x{Hh}, {a.spp} jittered camera rays per pixel, {a.lights} lights, drone/treasure/ground scene"},
-           "dtype": "f32", "frames": rows,
+           "dtype": "f32", "frames": rows, "roofline": rows[0]["roofline"], "cpu_baseline": cpu,
            "parity": "unpinned beyond 1 sample and 1 light: the reference has one sample at the pixel centre and one light "
                      "(scene.c:61-62, scene.h:17); at 1 spp / 1 light this kernel's frame equals the reference's, elsewhere it is "
                      "checked against this repository's own CPU restatement of the sampling rule"}
