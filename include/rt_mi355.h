@@ -327,7 +327,9 @@ int rt_last_counters(rt_ctx* ctx, rt_counters* out);
  * must hold 16 bytes per tile of the frames rendered; NULL switches tracing off. */
 int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
 
-/* Tunables, by name: "variant" (kernel variant id of rt_render_frame, 0 <= id < "n_variants"), "block"
+/* Tunables, by name: "variant" (kernel variant id of rt_render_frame, 0 <= id < "n_variants": 0 = one lane per pixel, 3 = the
+ * same with cooperative tiles where rays are long, the default; the other ids are experiments that lost against these two and
+ * are only in builds made with EXPERIMENTAL=1 -- read-only option "experimental_variants" says whether -- otherwise they run variant 0), "block"
  * (threads per workgroup: 64, 128 or 256), "timing" (record HIP events around each launch, default 1),
  * "coop" (variant 3: 0 off, 1 cooperative tiles where primary or shadow rays can meet a big mesh,
  * 2 primary rays only), "budget" (variant 4: node visits one lane spends on a pixel before the pixel is

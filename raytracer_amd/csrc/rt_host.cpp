@@ -721,7 +721,7 @@ int render_frame_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* ligh
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    if (cfg.variant == 4 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER | RT_FLAG_VERIFY_SKIPS)) == 0) {
+    if (kExperimentalVariants && cfg.variant == 4 && (flags & (RT_FLAG_COUNT_WORK | RT_FLAG_REFERENCE_ORDER | RT_FLAG_VERIFY_SKIPS)) == 0) {
         const size_t pixels = (size_t)width * (size_t)height;
         if (pixels > ctx->defer_capacity) {
             RT_HIP(ctx, hipDeviceSynchronize());          // an earlier frame may still be reading the old list
@@ -1340,6 +1340,7 @@ int rt_get_option(const rt_ctx* ctx, const char* name, int* value) {
     if (!strcmp(name, "batch_rows")) { *value = ctx->batch_rows; return RT_OK; }
     if (!strcmp(name, "budget")) { *value = ctx->budget; return RT_OK; }
     if (!strcmp(name, "n_variants")) { *value = kNumVariants; return RT_OK; }
+    if (!strcmp(name, "experimental_variants")) { *value = kExperimentalVariants; return RT_OK; }
     if (!strcmp(name, "default_variant")) { *value = kDefaultVariant; return RT_OK; }
     return RT_ERR_INVALID;
 }

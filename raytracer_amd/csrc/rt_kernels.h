@@ -7,7 +7,12 @@
 
 namespace rt {
 
-constexpr int kNumVariants = 10;     // kernel variants selectable through LaunchConfig::variant
+constexpr int kNumVariants = 10;     // kernel variant ids accepted by LaunchConfig::variant (1, 2, 4..9: experiments, see rt_kernels.hip)
+#if defined(RT_EXPERIMENTAL_VARIANTS)
+constexpr int kExperimentalVariants = 1;
+#else
+constexpr int kExperimentalVariants = 0;
+#endif
 constexpr int kDefaultVariant = 3;
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 

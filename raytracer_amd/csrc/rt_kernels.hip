@@ -3,7 +3,9 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (float results are compared
 // bit-for-bit with a CPU build that has no FMA contraction).
 //
-// Variants (LaunchConfig::variant):
+// Variants (LaunchConfig::variant).  0 and 3 are the product; 1, 2 and 4..9 are experiments that lost against them (measurements in
+// the repository's design notes) and are compiled only with -DRT_EXPERIMENTAL_VARIANTS (make EXPERIMENTAL=1) -- without it their
+// ids run variant 0.
 //   0  render_direct   one thread per pixel, one 8x8 tile per wave, nodes read through the
 //                      vector cache.  Works for any scene the packer accepts.
 //   1  render_resident persistent workgroups, one per CU, 16 waves each.  The PairNodes of the
@@ -444,6 +446,7 @@ hipError_t launch_instanced(const FrameArgs& A, const InstancedArgs& I, const Sc
     return hipGetLastError();
 }
 
+#if defined(RT_EXPERIMENTAL_VARIANTS)
 // ------------------------------------------------------------------------------------------
 // Variants 5..9: variant 0 tuned for occupancy.  Frames are independent, so a caller that renders
 // an animation can keep several frames in flight on different streams; the frame rate is then
@@ -509,6 +512,8 @@ static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const Outp
     hipLaunchKernelGGL((render_lean<BLOCK, DEPTH, LB, MINW>), dim3(blocks), dim3(BLOCK), lds, stream, A, S, O);
     return hipGetLastError();
 }
+
+#endif  // RT_EXPERIMENTAL_VARIANTS
 
 // ------------------------------------------------------------------------------------------
 // Batched frames: one launch renders n_frames frames of the same size into consecutive images.
@@ -858,6 +863,7 @@ static hipError_t launch_tiles(const FrameArgs& A, const SceneArgs& S, const Out
     return hipGetLastError();
 }
 
+#if defined(RT_EXPERIMENTAL_VARIANTS)
 // ------------------------------------------------------------------------------------------
 // Variant 4: two passes.  Pass 1 renders every tile with one lane per pixel, except that a pixel
 // whose rays together need more than FrameArgs::defer_budget node visits is abandoned and appended to a list
@@ -1062,6 +1068,10 @@ static hipError_t launch_resident(const FrameArgs& A, const SceneArgs& S, const 
 
 bool resident_fits(const SceneArgs& S) { return resident_lds_bytes(S) <= kMaxLdsBytes; }
 
+#else
+bool resident_fits(const SceneArgs&) { return false; }
+#endif  // RT_EXPERIMENTAL_VARIANTS
+
 hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPlanes& O, const LaunchConfig& cfg, hipStream_t stream) {
     if (A.width <= 0 || A.height <= 0) return hipErrorInvalidValue;
     const bool verify = (A.flags & RT_FLAG_VERIFY_SKIPS) != 0;
@@ -1070,6 +1080,9 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
     if ((count || verify) && !O.counters) return hipErrorInvalidValue;
     if (verify) return A.n_rects != 0 ? hipErrorInvalidValue : launch_direct<64>(A, S, O, false, false, true, stream);   // one lane per ray
     int variant = cfg.variant;
+#if !defined(RT_EXPERIMENTAL_VARIANTS)
+    if (variant != 3) variant = 0;                             // the experiments are not in this build
+#else
     if ((variant == 1 || variant == 2) && (!cfg.queue || !resident_fits(S))) variant = 0;     // scene too large for LDS
     if (variant != 3 && A.n_rects != 0) return hipErrorInvalidValue;
     // Work counts and the reference's visiting order are defined for one lane per ray.
@@ -1087,7 +1100,9 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
         }
     }
     if (variant == 4 && (!cfg.defer || !cfg.defer_items || (long long)cfg.defer_capacity < (long long)A.width * A.height)) return hipErrorInvalidValue;
+#endif
     switch (variant) {
+#if defined(RT_EXPERIMENTAL_VARIANTS)
         case 4:
             if (cfg.block == 64) return launch_two_pass<64>(A, S, O, cfg, stream);
             if (cfg.block == 128) return launch_two_pass<128>(A, S, O, cfg, stream);
@@ -1096,6 +1111,7 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
             return launch_resident<0>(A, S, O, cfg, count, full, stream);
         case 2:
             return launch_resident<1>(A, S, O, cfg, count, full, stream);
+#endif
         case 3:
             if (cfg.block == 64) return launch_tiles<64>(A, S, O, count, full, stream);
             if (cfg.block == 128) return launch_tiles<128>(A, S, O, count, full, stream);
