@@ -220,6 +220,8 @@ static const MaskCase kMasks[] = {
     {"even32", 0x5555555555555555ull, 32},
     {"low16", 0x000000000000FFFFull, 16},
     {"16+16", 0x0000FFFF0000FFFFull, 32},
+    {"low12", 0xFFFull, 12},
+    {"low9", 0x1FFull, 9},
     {"low8", 0xFFull, 8},
     {"low4", 0xFull, 4},
     {"low2", 0x3ull, 2},
@@ -258,10 +260,10 @@ int main(int argc, char** argv) {
     CHECK(hipDeviceSynchronize());
     for (int op = 0; op < OP_COUNT; op++) {
         for (int mi = 0; mi < n_masks; mi++) {
-            if (pmc && mi != 0 && mi != 1 && mi != 4 && mi != 9) continue;
+            if (pmc && mi != 0 && mi != 1 && mi != 4 && mi != 11) continue;
             for (int wi = 0; wi < n_wave_counts; wi++) {
                 const int W = wave_counts[wi];
-                if (!pmc && W != 8 && mi > 1 && mi != 9) continue;          // lower occupancies for the full mask, half a wave and one lane only
+                if (!pmc && W != 8 && mi > 1 && mi != 11) continue;          // lower occupancies for the full mask, half a wave and one lane only
                 const int blocks = cus * W;
                 hipEvent_t e0, e1;
                 CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
