@@ -2,7 +2,7 @@
 """How long the leaf lists of a light-space grid would be, against what shadow rays cost today.
 
 A directional light's shadow rays are parallel in a mesh's own space, so a 2-D grid across the light direction could name,
-per cell, the reference leaves (accel/bvh.c:31-45: up to four triangles, boxes as the median split leaves them) whose boxes
+per cell, the reference leaves (accel/bvh.c:18-55: up to four triangles, split at the mean centroid along the longest axis) whose boxes
 a ray through the cell can pass; the any-hit query would then test the listed leaf boxes instead of walking the tree.  This
 script measures the lists such a grid would hold for the animation's meshes (raytracer.c:41-52) -- the footprint of a leaf
 is the rectangle around its box's eight corners projected along the light -- for three grid sizes and three frames.
