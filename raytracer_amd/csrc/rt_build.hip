@@ -413,7 +413,7 @@ __global__ void k_records(const rt_triangle* tris, const uint32_t* prio, int32_t
     const rt_triangle s = tris[i];
     TriRec t;
     t.v0[0] = s.v0.x; t.v0[1] = s.v0.y; t.v0[2] = s.v0.z; t.prio = prio[i];
-    t.e1[0] = s.v1.x - s.v0.x; t.e1[1] = s.v1.y - s.v0.y; t.e1[2] = s.v1.z - s.v0.z; t.pad1 = 0.0f;      // ray.c:45-46
+    t.e1[0] = s.v1.x - s.v0.x; t.e1[1] = s.v1.y - s.v0.y; t.e1[2] = s.v1.z - s.v0.z; t.pad1 = __uint_as_float((uint32_t)i);      // ray.c:45-46; the triangle's id
     t.e2[0] = s.v2.x - s.v0.x; t.e2[1] = s.v2.y - s.v0.y; t.e2[2] = s.v2.z - s.v0.z; t.pad2 = 0.0f;
     tr[i] = t;
     AttrRec a;

@@ -18,6 +18,8 @@ using namespace rt;
 
 // the fast build of the kernels (rt_kernels_fast.hip)
 extern "C" hipError_t rt_fast_launch_render(const void* frame_args, const void* scene_args, const void* planes, const void* launch_config, hipStream_t stream);
+extern "C" hipError_t rt_fast_launch_instanced(const void* frame_args, const void* instanced_args, const void* scene_args, const void* planes, int32_t* hit_tri,
+                                               int tlas_stack_entries, int block, int wave_tiles, hipStream_t stream);
 extern "C" hipError_t rt_fast_launch_batch(const void* d_frames, int n_frames, int width, int height, const void* scene_args, uint8_t* rgb,
                                            size_t frame_stride, int first_row, int chunk, int swizzle, int block, hipStream_t stream);
 
@@ -37,6 +39,10 @@ struct DeviceMesh {
     uint32_t* d_grid = nullptr;    // flat meshes: entry references per cell (Packer::build_grid)
     MeshArgs proto;          // static part filled at upload; placement filled per frame
     int32_t n_tris = 0, n_pairs = 0;
+    // the tree over the triangles themselves that the fast build walks (Packer::build_loose) and its own copy of the triangle
+    // records; the ordinary entry and no copy where there is none
+    uint32_t loose_root = kLeafBit, loose_pairs = 0;
+    TriRec* d_loose_tris = nullptr;
 };
 
 }  // namespace
@@ -164,6 +170,7 @@ void free_mesh(DeviceMesh& m) {
     if (m.d_attrs) (void)hipFree(m.d_attrs);
     if (m.d_texels) (void)hipFree(m.d_texels);
     if (m.d_grid) (void)hipFree(m.d_grid);
+    if (m.d_loose_tris) (void)hipFree(m.d_loose_tris);
     m = DeviceMesh();
 }
 
@@ -207,6 +214,13 @@ int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tr
     dm.proto.root_ref = pk.root_ref; dm.proto.ref_root = pk.ref_root;
     dm.proto.empty = pk.empty ? 1u : 0u;
     dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.tree_pairs;
+    if (dm.d_loose_tris) { (void)hipFree(dm.d_loose_tris); dm.d_loose_tris = nullptr; }
+    dm.loose_root = pk.root_ref; dm.loose_pairs = pk.tree_pairs;
+    if (!pk.loose_tris.empty()) {
+        const int lst = upload_array(ctx, pk.loose_tris, &dm.d_loose_tris);
+        if (lst != RT_OK) return lst;
+        dm.loose_root = pk.loose_root; dm.loose_pairs = pk.loose_pairs;
+    }
     return RT_OK;
 }
 
@@ -251,6 +265,8 @@ int build_into(rt_ctx* ctx, DeviceMesh& dm, const rt_triangle* tris, int32_t n, 
                 dm.proto.root_ref = both.root_ref; dm.proto.ref_root = both.ref_root;
                 dm.depth = both.depth; dm.n_pairs = (int32_t)both.tree_pairs;
             }
+            if (dm.d_loose_tris) { (void)hipFree(dm.d_loose_tris); dm.d_loose_tris = nullptr; }
+            dm.loose_root = dm.proto.root_ref; dm.loose_pairs = (uint32_t)dm.n_pairs;
             return RT_OK;
         }
         if (st != RT_ERR_UNSUPPORTED) return fail(ctx, st, why);
@@ -335,16 +351,32 @@ void frame_shadow_rects(const rt_transform* transforms, int32_t n_transforms, Fr
         mesh_shadow_rect(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max, slo, shi, A, A.vis_shadow[m]);
 }
 
+// Whether a call with these flags runs the fast build of the kernels (option "fast"): the self-checking mode compares with the
+// reference's way, and RT_FLAG_REFERENCE_ORDER asks for the reference's own walk; both stay with the exact build.
+bool runs_fast(const rt_ctx* ctx, uint32_t flags) { return ctx->fast && !(flags & (RT_FLAG_VERIFY_SKIPS | RT_FLAG_REFERENCE_ORDER)); }
+
+// The fast build enters a mesh through the tree over its triangles themselves, where the mesh has one, and reads that
+// tree's copy of the triangle records.  Every walk of such a frame goes through it: the leaves of the mesh's other trees
+// index the records in the reference's order.
+void enter_loose_tree(const DeviceMesh& dm, MeshArgs& M) {
+    if (!dm.d_loose_tris) return;
+    M.root_ref = M.ref_root = dm.loose_root;
+    M.pair_count = dm.loose_pairs;
+    M.tris = dm.d_loose_tris;
+    M.res_pairs = M.res_tris = kNotResident;
+}
+
 // Per-frame constants: camera basis, light, and each mesh's placement (inverse matrices, camera
 // origin and light direction in mesh space).
 void fill_frame(const rt_ctx* ctx, const rt_camera& camera, const rt_light& light, const rt_transform* transforms, int32_t n_transforms,
-                int32_t width, int32_t height, uint32_t flags, FrameArgs& A) {
+                int32_t width, int32_t height, uint32_t flags, FrameArgs& A, bool fast_kernels = false) {
     memset(&A, 0, sizeof(A));
     fill_camera(camera, light, width, height, A);
     A.n_mesh = n_transforms;
     A.flags = flags;
     for (int32_t m = 0; m < n_transforms; m++) {
         A.mesh[m] = ctx->meshes[(size_t)m].proto;
+        if (fast_kernels) enter_loose_tree(ctx->meshes[(size_t)m], A.mesh[m]);
         fill_placement(transforms[m], A, A.mesh[m]);
         if (ctx->screen_cull) mesh_screen_rect(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max, A, A.vis[m]);
         else { A.vis[m][0] = 0; A.vis[m][1] = 0; A.vis[m][2] = (width + 7) / 8; A.vis[m][3] = (height + 7) / 8; }
@@ -677,7 +709,7 @@ int render_frame_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* ligh
     const SceneArgs S = scene_args(ctx);
 
     FrameArgs A;
-    fill_frame(ctx, *camera, *light, transforms, n_transforms, width, height, flags, A);
+    fill_frame(ctx, *camera, *light, transforms, n_transforms, width, height, flags, A, runs_fast(ctx, flags));
     const bool share = stride != 1 || offset != 0;        // some of the frame's strips: plain tiles in launch order
     if (share && !take_strips(A, stride, offset)) return RT_OK;
     LaunchConfig cfg = ctx->cfg;
@@ -737,7 +769,7 @@ int render_frame_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* ligh
         A.defer_budget = ctx->budget;
     }
     // the self-check compares against the reference's own arithmetic: it always runs the exact build
-    hipError_t le = ctx->fast && !(flags & RT_FLAG_VERIFY_SKIPS) ? rt_fast_launch_render(&A, &S, &O, &cfg, s) : launch_render(A, S, O, cfg, s);
+    hipError_t le = runs_fast(ctx, flags) ? rt_fast_launch_render(&A, &S, &O, &cfg, s) : launch_render(A, S, O, cfg, s);
     if (le != hipSuccess) {
         // leave the work-distribution words of the persistent / two-pass variants in their idle state
         (void)hipDeviceSynchronize();
@@ -827,7 +859,7 @@ int render_frames_impl(rt_ctx* ctx, const rt_camera* camera, const rt_light* lig
     bool bounded = true;
     for (int32_t f = 0; f < n_frames; f++) {
         const rt_transform* tf = transforms ? transforms + (size_t)f * (size_t)n_transforms : nullptr;
-        fill_frame(ctx, *camera, *light, tf, n_transforms, width, height, 0u, h[f]);
+        fill_frame(ctx, *camera, *light, tf, n_transforms, width, height, 0u, h[f], ctx->fast != 0);
         const int row = first_heavy_row(tf, n_transforms, h[f]);
         h[f].first_tile_row = row > 0 && row < (height + 7) / 8 ? row : 0;
         if (row < 0) bounded = false;
@@ -995,6 +1027,7 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
     ctx->inst_cache.resize((size_t)n_instances);
     for (int32_t i = 0; i < n_instances; i++) {
         inst[i] = ctx->meshes[(size_t)instances[i].mesh].proto;
+        if (runs_fast(ctx, flags)) enter_loose_tree(ctx->meshes[(size_t)instances[i].mesh], inst[i]);
         InstanceCache& c = ctx->inst_cache[(size_t)i];
         const bool same = c.valid && memcmp(&c.transform, &instances[i].transform, sizeof(rt_transform)) == 0 &&
                           memcmp(c.root_min, inst[i].root_min, 12) == 0 && memcmp(c.root_max, inst[i].root_max, 12) == 0;
@@ -1033,7 +1066,8 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    hipError_t le = launch_instanced(A, I, S, O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, ctx->instanced_wave, s);
+    hipError_t le = runs_fast(ctx, flags) ? rt_fast_launch_instanced(&A, &I, &S, &O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, ctx->instanced_wave, s)
+                                          : launch_instanced(A, I, S, O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, ctx->instanced_wave, s);
     if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
     RT_HIP(ctx, hipEventRecord(ctx->inst_done[slot], s));

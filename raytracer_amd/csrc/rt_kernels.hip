@@ -1128,12 +1128,18 @@ hipError_t launch_render(const FrameArgs& A, const SceneArgs& S, const OutputPla
 
 #if defined(RT_FAST)
 // The fast build of this file (rt_kernels_fast.hip: fused multiply-adds, approximate division and square root, the
-// slab test above; `rt` is renamed for the whole translation unit) is reached through these two entry points.  The
+// slab test above; `rt` is renamed for the whole translation unit) is reached through these three entry points.  The
 // argument structures are the ones of the exact build, layout for layout.
 extern "C" hipError_t rt_fast_launch_render(const void* frame_args, const void* scene_args, const void* planes, const void* launch_config,
                                             hipStream_t stream) {
     return rt::launch_render(*static_cast<const rt::FrameArgs*>(frame_args), *static_cast<const rt::SceneArgs*>(scene_args),
                              *static_cast<const rt::OutputPlanes*>(planes), *static_cast<const rt::LaunchConfig*>(launch_config), stream);
+}
+extern "C" hipError_t rt_fast_launch_instanced(const void* frame_args, const void* instanced_args, const void* scene_args, const void* planes, int32_t* hit_tri,
+                                               int tlas_stack_entries, int block, int wave_tiles, hipStream_t stream) {
+    return rt::launch_instanced(*static_cast<const rt::FrameArgs*>(frame_args), *static_cast<const rt::InstancedArgs*>(instanced_args),
+                                *static_cast<const rt::SceneArgs*>(scene_args), *static_cast<const rt::OutputPlanes*>(planes), hit_tri, tlas_stack_entries,
+                                block, wave_tiles, stream);
 }
 extern "C" hipError_t rt_fast_launch_batch(const void* d_frames, int n_frames, int width, int height, const void* scene_args, uint8_t* rgb,
                                            size_t frame_stride, int first_row, int chunk, int swizzle, int block, hipStream_t stream) {

@@ -43,7 +43,8 @@ struct alignas(16) TriRec {
     float v0[3];
     uint32_t prio;        // winner among equal-t hits = highest prio (see host packer)
     float e1[3];
-    float pad1;
+    float pad1;           // bits: the triangle's index in the mesh's own triangle order (what a hit reports); read by the fast build,
+                          // whose tree keeps its records in another order -- the exact build takes the record's position
     float e2[3];
     float pad2;
 };

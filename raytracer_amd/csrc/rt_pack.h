@@ -5,6 +5,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -24,6 +25,7 @@ static_assert(sizeof(rt_flat_node) == 40, "flat node is 40 bytes");
 static_assert(sizeof(rt_transform) == 24 && sizeof(rt_camera) == 40 && sizeof(rt_light) == 24, "reference struct sizes");
 
 inline F3 f3(const rt_vec3& v) { return f3(v.x, v.y, v.z); }
+inline float bits_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 // ------------------------------------------------------------------------------------------
 // Reference builder (accel/bvh.c:4-59).  The tree is produced in creation order
@@ -124,6 +126,13 @@ struct PackedMesh {
     uint32_t grid_axis = 3;
     int32_t grid_n = 0;
     float grid_lo[2] = {0, 0}, grid_inv[2] = {0, 0}, grid_slack[2] = {0, 0}, grid_bmax[2] = {0, 0};
+    // A third tree, behind the other two in `pairs`, for renderings that need not be bit-identical (see Packer::build_loose):
+    // its leaves index loose_tris, the triangle records in that tree's own order.  loose_root = root_ref (and loose_tris
+    // empty) where there is none.
+    uint32_t loose_root = kLeafBit;
+    uint32_t loose_pairs = 0;
+    int loose_depth = 0;
+    std::vector<TriRec> loose_tris;
 };
 
 // The grid fields of a MeshArgs from a packed mesh; d_grid = where pk.grid lives for the code that will traverse.
@@ -151,7 +160,7 @@ public:
             TriRec& t = out_.tris[(size_t)i];
             const F3 v0 = f3(s.v0), e1 = sub(f3(s.v1), v0), e2 = sub(f3(s.v2), v0);   // ray.c:45-46
             t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z; t.prio = 0;
-            t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z; t.pad1 = 0;
+            t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z; t.pad1 = bits_as_float((uint32_t)i);   // the triangle's id (see TriRec)
             t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z; t.pad2 = 0;
             AttrRec& a = out_.attrs[(size_t)i];
             a.t0[0] = s.t0.u; a.t0[1] = s.t0.v; a.t1[0] = s.t1.u; a.t1[1] = s.t1.v; a.t2[0] = s.t2.u; a.t2[1] = s.t2.v;
@@ -176,6 +185,8 @@ public:
         if (out_.depth + 2 > kStackDepth || out_.depth > RT_MAX_TREE_DEPTH) { err = "BVH deeper than the traversal stack"; return RT_ERR_UNSUPPORTED; }
         if (regroup_ && leaves_ok_ && leaves_.size() >= 4 && leaves_.size() <= ((size_t)1 << 23)) regroup();
         if (regroup_) build_grid();
+        out_.loose_root = out_.root_ref; out_.loose_pairs = out_.tree_pairs;
+        if (regroup_ && out_.grid_axis == 3) build_loose();
         return RT_OK;
     }
 
@@ -311,7 +322,12 @@ private:
     uint32_t regroup_range(std::vector<PairNode>& fast, uint32_t base, size_t first, size_t count, int depth, int& deepest, float* lo, float* hi) {
         LeafItem* it = leaves_.data() + first;
         for (int a = 0; a < 3; a++) { lo[a] = it[0].lo[a]; hi[a] = it[0].hi[a]; }
-        if (count == 1) return it[0].ref;
+        if (count == 1 && items_per_leaf_ == 0) return it[0].ref;
+        if (items_per_leaf_ > 0 && count <= items_per_leaf_) {          // build_loose: the items themselves, in their final order, are the leaf
+            for (size_t i = 1; i < count; i++)
+                for (int a = 0; a < 3; a++) { lo[a] = it[i].lo[a] < lo[a] ? it[i].lo[a] : lo[a]; hi[a] = it[i].hi[a] > hi[a] ? it[i].hi[a] : hi[a]; }
+            return leaf_ref((uint32_t)first, (uint32_t)count);
+        }
         float clo[3], chi[3];
         for (int a = 0; a < 3; a++) { clo[a] = chi[a] = it[0].lo[a] + it[0].hi[a]; }
         for (size_t i = 1; i < count; i++)
@@ -361,8 +377,9 @@ private:
         // A run of lopsided splits could take the tree past the depth the traversal stack covers (and this recursion past its
         // own stack): from the point where only halving still fits below the limit, halve.
         int halvings = 0;
-        while (((size_t)1 << halvings) < count) halvings++;
-        if (depth + halvings >= RT_MAX_TREE_DEPTH) best_axis = -1;
+        const size_t unit = items_per_leaf_ ? items_per_leaf_ : 1;
+        while ((unit << halvings) < count) halvings++;
+        if (depth + halvings >= depth_cap_) best_axis = -1;
         if (best_axis >= 0) {
             const int a = best_axis;
             const float extent = chi[a] - clo[a];
@@ -419,6 +436,72 @@ private:
         out_.tree_pairs = shift;
         out_.pairs.swap(fast);
         if (deepest > out_.depth) out_.depth = deepest;
+    }
+
+    // ---- a tree of the triangles themselves -----------------------------------------------------------
+    // The reference tests a triangle when the ray passes the box of the triangle's LEAF, and its leaves are what a split at
+    // the mean centroid leaves over (bvh.c:19-55): up to four triangles that need not be neighbours, in a box that overlaps
+    // its neighbours'.  A tree built over the triangles themselves by the surface-area split of regroup_range, with leaves of
+    // up to kLooseLeafTris triangles that ARE neighbours, tests fewer boxes and fewer triangles -- but not the same ones: a ray
+    // that grazes a triangle's edge can be accepted by the triangle test (ray.c:42-67) and yet fail the slab test of a tight
+    // box around it, or the other way round, so single pixels along silhouettes may differ from the reference's.  Only the
+    // fast build of the kernels, whose arithmetic is not the reference's either, walks this tree.  Its leaves index
+    // loose_tris, a copy of the triangle records in the tree's order; each record carries the triangle's id (TriRec::pad1),
+    // which is what a hit reports, so attributes and hit ids are the reference's.  Triangles that no leaf of the reference's
+    // tree holds are left out.  Appended to `pairs` behind the other trees, which keep their places.  Not built for flat
+    // meshes (their grid already leads to single leaves).
+    static constexpr size_t kLooseLeafTris = 8;      // measured: 4: 0.736 ms, 6: 0.732, 8: 0.662, 12: 0.663, 16: 0.676 per 8-frame launch of the animation
+    void build_loose() {
+        if (out_.empty || !tris_ || n_tris_ < 8 || (out_.root_ref & kLeafBit)) return;
+        std::vector<LeafItem> items;
+        items.reserve((size_t)n_tris_);
+        for (int32_t i = 0; i < n_tris_; i++) {
+            if (!covered_[(size_t)i]) continue;
+            const rt_vec3* corner = &tris_[i].v0;
+            LeafItem it;
+            it.lo[0] = it.hi[0] = corner[0].x; it.lo[1] = it.hi[1] = corner[0].y; it.lo[2] = it.hi[2] = corner[0].z;
+            for (int c = 1; c < 3; c++) {
+                const float v[3] = {corner[c].x, corner[c].y, corner[c].z};
+                for (int a = 0; a < 3; a++) { it.lo[a] = v[a] < it.lo[a] ? v[a] : it.lo[a]; it.hi[a] = v[a] > it.hi[a] ? v[a] : it.hi[a]; }
+            }
+            it.ref = (uint32_t)i;
+            items.push_back(it);
+        }
+        if (items.size() < 8 || out_.pairs.size() + items.size() >= (size_t)kLeafBit) return;
+        leaves_.swap(items);
+        items_per_leaf_ = loose_leaf_tris();
+        // no deeper than the mesh's other trees, if a balanced tree fits below that: the traversal stack of every kernel,
+        // the exact ones included, is sized by the deepest tree of the scene
+        int balanced = 1;
+        while ((items_per_leaf_ << balanced) < leaves_.size()) balanced++;
+        depth_cap_ = out_.depth > balanced ? out_.depth : balanced + 1;
+        if (depth_cap_ > RT_MAX_TREE_DEPTH) depth_cap_ = RT_MAX_TREE_DEPTH;
+        std::vector<PairNode> loose(leaves_.size() - 1);
+        memset(loose.data(), 0, loose.size() * sizeof(PairNode));          // records that multi-triangle leaves leave unused
+        int deepest = 0;
+        float lo[3], hi[3];
+        const uint32_t root = regroup_range(loose, 0, 0, leaves_.size(), 0, deepest, lo, hi);
+        items_per_leaf_ = 0;
+        depth_cap_ = RT_MAX_TREE_DEPTH;
+        leaves_.swap(items);                                               // items: the triangles in the tree's order
+        if ((root & kLeafBit) || deepest + 2 > kStackDepth || deepest > RT_MAX_TREE_DEPTH) return;
+        const uint32_t shift = (uint32_t)out_.pairs.size();
+        for (PairNode p : loose) {
+            if (!(p.lref & kLeafBit)) p.lref += shift;
+            if (!(p.rref & kLeafBit)) p.rref += shift;
+            out_.pairs.push_back(p);
+        }
+        out_.loose_tris.resize(items.size());
+        for (size_t i = 0; i < items.size(); i++) out_.loose_tris[i] = out_.tris[items[i].ref];
+        out_.loose_root = root + shift;
+        out_.loose_pairs = (uint32_t)loose.size();
+        out_.loose_depth = deepest;
+        if (deepest > out_.depth) out_.depth = deepest;
+    }
+    static size_t loose_leaf_tris() {
+        const char* e = getenv("RT_LOOSE_LEAF_TRIS");                      // experiments only
+        const long v = e ? atol(e) : 0;
+        return v >= 1 && v <= 16 ? (size_t)v : kLooseLeafTris;
     }
 
     // ---- flat meshes: where a ray can start its walk ------------------------------------------------
@@ -529,6 +612,8 @@ private:
     std::vector<uint8_t> covered_, visited_;
     uint32_t next_prio_ = 0;
     bool regroup_ = false, leaves_ok_ = true;
+    int depth_cap_ = RT_MAX_TREE_DEPTH;  // regroup_range: no chain of nodes longer than this
+    size_t items_per_leaf_ = 0;          // regroup_range: 0 = every item is a leaf reference of its own; n = up to n items form a leaf
     std::vector<LeafItem> leaves_;
 };
 

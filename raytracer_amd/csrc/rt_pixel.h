@@ -46,6 +46,20 @@ struct Work {
     uint32_t bad_inst = 0;       // the walk over the instance hierarchy ends differently from the reference's loop over all instances
 };
 
+RT_HD float uint_as_f32(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; memcpy(&f, &u, 4); return f;
+#endif
+}
+RT_HD uint32_t f32_as_uint(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u; memcpy(&u, &f, 4); return u;
+#endif
+}
 // Reads through the pointers a MeshArgs carries (triangles, attributes, texels, grid cells).  Device code reads such a
 // pointer from memory first, so the compiler cannot know which memory it points to and would use FLAT accesses; those
 // count against both of a wave's memory counters, and every wait for an LDS read (the traversal stack) would then wait
@@ -62,10 +76,19 @@ __device__ __forceinline__ V global_read(const void* base, size_t byte_offset) {
 __device__ __forceinline__ TriRec read_tri(const TriRec* tris, uint32_t index) {
     const size_t at = (size_t)index * sizeof(TriRec);
     const f32x4 a = global_read<f32x4>(tris, at);
-    const f32x3 b = global_read<f32x3>(tris, at + 16), c = global_read<f32x3>(tris, at + 32);
+#if defined(RT_FAST)
+    const f32x4 b = global_read<f32x4>(tris, at + 16);                     // with the triangle's id
+#else
+    const f32x3 b = global_read<f32x3>(tris, at + 16);
+#endif
+    const f32x3 c = global_read<f32x3>(tris, at + 32);
     TriRec t;
     t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z; t.prio = __float_as_uint(a.w);
+#if defined(RT_FAST)
+    t.e1[0] = b.x; t.e1[1] = b.y; t.e1[2] = b.z; t.pad1 = b.w;
+#else
     t.e1[0] = b.x; t.e1[1] = b.y; t.e1[2] = b.z; t.pad1 = 0.0f;
+#endif
     t.e2[0] = c.x; t.e2[1] = c.y; t.e2[2] = c.z; t.pad2 = 0.0f;
     return t;
 }
@@ -227,7 +250,12 @@ RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, 
                 }
             } else if (t < q.best_t || (q.found && t == q.best_t && T[k].prio > q.hit.prio)) {
                 q.best_t = t; q.found = true;
-                q.hit.t = t; q.hit.u = u; q.hit.v = v; q.hit.tri = first + i0 + k; q.hit.prio = T[k].prio;
+                q.hit.t = t; q.hit.u = u; q.hit.v = v; q.hit.prio = T[k].prio;
+#if defined(RT_FAST) || !defined(__HIP_DEVICE_COMPILE__)
+                q.hit.tri = f32_as_uint(T[k].pad1);          // the record names its triangle: the tree walked may keep its records in its own order
+#else
+                q.hit.tri = first + i0 + k;
+#endif
                 if (CULL && t < q.bound) q.limit = cull_limit(t);
             }
         }
@@ -264,20 +292,6 @@ RT_HD uint32_t entry_ref(const MeshArgs& M, F3 d) {
     return (d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ? M.root_ref : M.ref_root;
 }
 
-RT_HD float uint_as_f32(uint32_t u) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __uint_as_float(u);
-#else
-    float f; memcpy(&f, &u, 4); return f;
-#endif
-}
-RT_HD uint32_t f32_as_uint(float f) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __float_as_uint(f);
-#else
-    uint32_t u; memcpy(&u, &f, 4); return u;
-#endif
-}
 RT_HD float comp(F3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
 // Where a ray starts its walk in a flat mesh (MeshArgs::grid, built by Packer::build_grid): the node stored for the cell

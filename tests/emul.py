@@ -77,6 +77,8 @@ def lib():
         L.emul_regroup_routes_agree.argtypes = [vp, i32, vp, i32]
         L.emul_work_plane.argtypes = [vp, vp]
         L.emul_work_plane.restype = None
+        L.emul_set_loose.argtypes = [vp, i32]
+        L.emul_set_loose.restype = None
         L.emul_set_vis_shrink.argtypes = [vp, i32]
         L.emul_set_vis_shrink.restype = None
         L.emul_damage_grid.argtypes = [vp, i32]
@@ -207,6 +209,10 @@ class Scene:
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_inst": inst, "hit_tri": tri, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(),
                 "tlas_pairs": pairs.value, "tlas_depth": depth.value}
+
+    def set_loose(self, on: bool):
+        """Rays enter every mesh through its tree of single triangles (what the kernels' fast build walks); not bit-exact."""
+        lib().emul_set_loose(self.h, 1 if on else 0)
 
     # deliberate damage, for the tests that the self-checking party (verify=True) notices wrong shortcuts
     def set_vis_shrink(self, tiles: int):

@@ -42,6 +42,7 @@ struct EmulScene {
     bool keep_hierarchy = false;       // instanced frames: the product's hierarchy kept from call to call
     float box_allowance = 0.0f;        // what the world boxes were widened by last time
     uint32_t* work_plane = nullptr;    // instanced frames: per pixel {box tests, triangle tests} of both rays, when set
+    bool loose = false;                // rays enter through the tree of single triangles (Packer::build_loose), as in the kernels' fast build
     int vis_shrink = 0;                // tests of the self-check: screen and shadow rectangles made this many tiles too small on every side
     StandingTlas standing;
     int hierarchy_reused = 0;          // calls that reused the kept tree
@@ -67,6 +68,7 @@ void emul_keep_hierarchy(void* s, int on) { ((EmulScene*)s)->keep_hierarchy = on
 int emul_hierarchy_reused(void* s) { return ((EmulScene*)s)->hierarchy_reused; }
 // Deliberate damage, for the tests that the self-checking party notices a wrong shortcut:
 // rectangles too small; a flat mesh's grid whose every cell names the first leaf only; the second tree's root with its left box moved out of every ray's way.
+void emul_set_loose(void* s, int on) { ((EmulScene*)s)->loose = on != 0; }
 void emul_set_vis_shrink(void* s, int tiles) { ((EmulScene*)s)->vis_shrink = tiles; }
 int emul_damage_grid(void* sp, int mesh) {
     EmulScene* s = (EmulScene*)sp;
@@ -102,10 +104,13 @@ int emul_regroup_routes_agree(const rt_triangle* tris, int32_t n_tris, const rt_
     if (Packer(tris, n_tris, nodes, n_nodes, a, true).run(err) != RT_OK) return -1;
     if (Packer(tris, n_tris, nodes, n_nodes, b, false).run(err) != RT_OK) return -1;
     const bool done = Packer::regroup_packed(b);
-    const bool had = a.root_ref != a.ref_root || a.tree_pairs != (uint32_t)a.pairs.size();
+    // run() may have appended the tree over the triangles themselves (Packer::build_loose), which the other route does not build
+    const size_t a_pairs = a.loose_tris.empty() ? a.pairs.size() : a.pairs.size() - a.loose_pairs;
+    const bool had = a.root_ref != a.ref_root || a.tree_pairs != (uint32_t)a_pairs;
     if (!done && !had) return 2;
-    if (a.pairs.size() != b.pairs.size() || a.root_ref != b.root_ref || a.ref_root != b.ref_root || a.tree_pairs != b.tree_pairs || a.depth != b.depth) return 1;
-    return memcmp(a.pairs.data(), b.pairs.data(), a.pairs.size() * sizeof(PairNode)) == 0 ? 0 : 1;
+    const bool same_depth = a.depth == b.depth || (!a.loose_tris.empty() && a.depth == a.loose_depth && a.depth > b.depth);
+    if (a_pairs != b.pairs.size() || a.root_ref != b.root_ref || a.ref_root != b.ref_root || a.tree_pairs != b.tree_pairs || !same_depth) return 1;
+    return memcmp(a.pairs.data(), b.pairs.data(), a_pairs * sizeof(PairNode)) == 0 ? 0 : 1;
 }
 
 int emul_mesh_add(void* sp, const rt_triangle* tris, int32_t n_tris, const rt_flat_node* nodes, int32_t n_nodes,
@@ -183,7 +188,9 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         M.pair_base = base; M.pair_count = E.pk.tree_pairs; base += (uint32_t)E.pk.pairs.size();
         M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
-        M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root;
+        if (s->loose && !E.pk.loose_tris.empty()) { M.root_ref = M.ref_root = E.pk.loose_root; M.tris = E.pk.loose_tris.data(); }
+        set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
         fill_placement(tfs[m], A, M);
         mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
     }
@@ -321,7 +328,9 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
         M.pair_base = base[(size_t)mesh_ids[i]]; M.pair_count = E.pk.tree_pairs;
         M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
-        M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root;
+        if (s->loose && !E.pk.loose_tris.empty()) { M.root_ref = M.ref_root = E.pk.loose_root; M.tris = E.pk.loose_tris.data(); }
+        set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
         fill_placement(tfs[i], A, M);
         if (!M.empty) { boxes.push_back(instance_box(tfs[i], M.root_min, M.root_max)); ids.push_back((uint32_t)i); }
     }

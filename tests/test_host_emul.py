@@ -631,3 +631,48 @@ def test_meshes_with_nan_and_infinite_vertices_through_the_host_build_of_the_pix
             s.close()
         n += 1
     assert n >= 30
+
+
+def test_tree_over_the_triangles_themselves_reaches_the_same_surfaces(po, meshes):
+    """The third tree (Packer::build_loose: surface-area splits over single triangles, leaves of up to eight neighbours,
+    its own copy of the triangle records) is what the kernels' fast build walks.  With the exact arithmetic of the CPU
+    build it must find the reference's hits except where a ray grazes an edge -- at least 99.99 % of camera rays, in
+    practice all of them on this scene -- report the reference's triangle ids (each record carries its own), and test
+    fewer boxes and triangles on the closed meshes.  The flat ground has no such tree: its grid already leads to leaves."""
+    s = emul.Scene(regroup=True)
+    for m in meshes:
+        assert s.add(m.tris, m.nodes, m.rgba) == 0
+    for f in (0, 45):
+        tfs = po.animation_transforms(f)
+        s.set_loose(False)
+        exact = s.render(po.default_camera(), po.default_light(), tfs, 480, 270)
+        s.set_loose(True)
+        loose = s.render(po.default_camera(), po.default_light(), tfs, 480, 270)
+        s.set_loose(False)
+        same = float((exact["hit_id"] == loose["hit_id"]).mean())
+        assert same >= 0.9999, (f, same)
+        assert float((np.abs(exact["rgb"].astype(np.int16) - loose["rgb"].astype(np.int16)).max(axis=2) <= 1).mean()) >= 0.999
+        assert loose["counters"]["slab_tests"] < exact["counters"]["slab_tests"]
+        assert loose["stack_high"] <= exact["stack_high"] + 1
+    # every triangle of a random soup is in exactly one leaf of that tree: a frame that looks at the soup from all around
+    # finds, triangle for triangle, what the reference's tree finds
+    rng = np.random.default_rng(11)
+    soup = np.zeros((400, 24), np.float32)
+    centre = rng.uniform(-1, 1, (400, 1, 3)).astype(np.float32)
+    soup[:, :9] = (centre + rng.uniform(-0.15, 0.15, (400, 3, 3)).astype(np.float32)).reshape(400, 9)
+    soup[:, 15:24] = np.tile(np.array([0, 1, 0], np.float32), 3)
+    tris, nodes = po.build_bvh(soup)
+    s2 = emul.Scene(regroup=True)
+    assert s2.add(tris, nodes, np.full((4, 4, 4), 200, np.uint8)) == 0
+    seen_exact, seen_loose = set(), set()
+    for cam_pos in ((3, 2, 3), (-3, 2, 3), (3, -2, -3), (-3, 1, -3), (0.1, 4, 0.1)):
+        cam = po.Camera(po.vec3(*cam_pos), po.vec3(0, 0, 0), po.vec3(0, 1, 0), 50.0)
+        tf = [po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))]
+        s2.set_loose(False)
+        a = s2.render(cam, po.default_light(), tf, 200, 200)
+        s2.set_loose(True)
+        b = s2.render(cam, po.default_light(), tf, 200, 200)
+        assert float((a["hit_id"] == b["hit_id"]).mean()) >= 0.999
+        seen_exact |= set(np.unique(a["hit_id"]).tolist())
+        seen_loose |= set(np.unique(b["hit_id"]).tolist())
+    assert len(seen_exact) > 300 and len(seen_exact ^ seen_loose) <= 2
