@@ -94,9 +94,10 @@ struct MeshArgs {
     float grid_slack[2];         // how far a ray's plane point may be off for the cell's entry to hold
     float grid_bmax[2];          // largest |coordinate| of the mesh on that axis
 };
-// A grid cell of a flat mesh holds a child reference (leaf or PairNode index) or, with this bit, a list of leaves:
-// bits 27..24 = count (1..kGridListMax), bits 23..0 = first record; the records (eight words each: leaf box min, max, leaf
-// reference, 0) follow the grid_n * grid_n cell words, rounded up to a multiple of eight words.
+// A grid cell of a flat mesh holds leaf_ref(0, 0) (nothing to test), a PairNode index (the walk starts there), or, with this
+// bit, a list of leaves: bits 27..24 = count (1..kGridListMax), bits 23..0 = first record; the records (eight words each: leaf
+// box min, max, leaf reference, mask of the leaf's triangles to test) follow the grid_n * grid_n cell words, rounded up to a
+// multiple of eight words.
 constexpr uint32_t kGridListBit = 0x40000000u;
 constexpr uint32_t kGridListMax = 8;
 constexpr uint32_t kNotResident = 0xFFFFFFFFu;

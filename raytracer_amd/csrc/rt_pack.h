@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <string>
 #include <future>
+#include <map>
 #include <system_error>
 #include <vector>
 
@@ -505,6 +506,80 @@ private:
     }
 
     // ---- flat meshes: where a ray can start its walk ------------------------------------------------
+    // Cells are padded by this share of their size on every side; half of it is what a ray's own uncertainty may use up.
+    static constexpr double kGridSlackShare = 64.0;
+
+    // Which triangles of a leaf a ray through a cell can be accepted by (ray.c:42-67) -- bit i for the leaf's i-th triangle.
+    // The ray meets the mesh's plane in X, inside the padded cell [rlo, rhi]; its uncertainty about X is at most `gate` per
+    // in-plane axis (16 u (|o| + |t d| + max |coordinate|), what grid_entry admits).  With the triangle's edges e1, e2 in the
+    // plane (component k exactly zero), the reference's u is [s, d, e2] / [e1, d, e2] with s = o - v0: the products that
+    // involve the ray's path to the plane cancel exactly in real arithmetic and to within 15 u (|o| + 3 |t d| + max
+    // |coordinate|, summed over both axes) times |d_k| |e2| in floats; the denominator is d_k D, D = e1 x e2, off by at most
+    // 3 u kappa of itself (kappa = (|e1_a e2_b| + |e1_b e2_a|) / |D|).  So a ray whose X lies farther than about (gate_a +
+    // gate_b) outside the line through v0 along e2 gets u < 0 for certain, likewise v < 0 beyond the line along e1, and
+    // u + v > 1 beyond the line v1 v2 if the distance also covers the factor (|e1| + |e2|) / |v2 - v1| by which the two
+    // errors add up there and kappa's share of the triangle's height.  The three lines are moved outward by
+    //     mu = 8 (gate_a + gate_b) max(1, (|e1| + |e2|) / |v2 - v1|) + 2^-18 (kappa + 1) (|e1| + |e2|)
+    // -- eight times the bound -- and the triangle is left out of the cell only if the padded cell lies entirely beyond one
+    // of the moved lines.  Triangles for which the argument does not hold (kappa or the factor above 4096: needles, edges of
+    // length zero, non-finite vertices) are always kept, as are all triangles of a leaf with more than 32.
+    uint32_t tri_mask(uint32_t leaf, int k, const int* ax, const double* rlo, const double* rhi, const double* gate) const {
+        const uint32_t first = leaf & 0x00FFFFFFu, count = (leaf >> 24) & 0x7Fu;
+        if (count == 0) return 0u;
+        if (count > 32 || out_.tris.size() < (size_t)first + count) return 0xFFFFFFFFu;
+        uint32_t mask = 0;
+        for (uint32_t i = 0; i < count; i++) {
+            const TriRec& t = out_.tris[(size_t)first + i];
+            bool keep = true;
+            const double p0[2] = {t.v0[ax[0]], t.v0[ax[1]]};
+            const double e1[2] = {t.e1[ax[0]], t.e1[ax[1]]}, e2[2] = {t.e2[ax[0]], t.e2[ax[1]]};
+            const double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1]), l2 = sqrt(e2[0] * e2[0] + e2[1] * e2[1]);
+            const double h[2] = {e2[0] - e1[0], e2[1] - e1[1]};
+            const double l3 = sqrt(h[0] * h[0] + h[1] * h[1]);
+            const double D = e1[1] * e2[0] - e1[0] * e2[1];
+            const double spread = fabs(e1[0] * e2[1]) + fabs(e1[1] * e2[0]);
+            const bool sound = t.e1[k] == 0.0f && t.e2[k] == 0.0f && std::isfinite(p0[0]) && std::isfinite(p0[1]) && std::isfinite(l1) &&
+                               std::isfinite(l2) && std::isfinite(l3) && l1 > 0 && l2 > 0 && l3 > 0 && fabs(D) > 0 && spread <= 4096.0 * fabs(D) &&
+                               l1 + l2 <= 4096.0 * l3;
+            if (sound) {
+                const double kappa = spread / fabs(D), worst = (l1 + l2) / l3;
+                const double mu = 8.0 * (gate[0] + gate[1]) * (worst > 1.0 ? worst : 1.0) + ldexp(1.0, -18) * (kappa + 1.0) * (l1 + l2);
+                // edges: (p, direction, a vertex on the inner side)
+                const double v1[2] = {p0[0] + e1[0], p0[1] + e1[1]}, v2[2] = {p0[0] + e2[0], p0[1] + e2[1]};
+                const double* from[3] = {p0, p0, v1};
+                const double* along[3] = {e2, e1, h};
+                const double len[3] = {l2, l1, l3};
+                const double* inner[3] = {v1, v2, p0};
+                for (int e = 0; e < 3 && keep; e++) {
+                    double nx = along[e][1] / len[e], ny = -along[e][0] / len[e];           // unit normal of the edge's line
+                    if (nx * (inner[e][0] - from[e][0]) + ny * (inner[e][1] - from[e][1]) > 0) { nx = -nx; ny = -ny; }   // pointing outward
+                    // the corner of the padded cell that lies least far out
+                    const double cx = nx > 0 ? rlo[0] : rhi[0], cy = ny > 0 ? rlo[1] : rhi[1];
+                    const double out = nx * (cx - from[e][0]) + ny * (cy - from[e][1]);
+                    if (out > mu) keep = false;
+                }
+            }
+            if (keep) mask |= 1u << i;
+        }
+        return mask;
+    }
+
+    // Whether every ray that grid_entry sends to a cell passes the slab test of a flat leaf box (record: min, max as float
+    // bits) whenever the plane's parameter ty is positive.  On the flat axis both slab parameters ARE ty (the same float
+    // expression as in grid_entry).  On an in-plane axis a the test needs ty between t1 = fl(fl(min_a - o_a) inv_a) and t2
+    // (max_a likewise); their real values differ from ty's by (X_a - min_a) / d_a and (max_a - X_a) / d_a, and the three
+    // roundings involved move them by at most 3 u (|o_a| + |ty d_a| + max |coordinate|) / |d_a| -- less than a fifth of
+    // what the ray's admitted uncertainty (gate_a = 16 u of the same sum) allows.  So if the padded cell keeps a distance
+    // of gate_a from the rectangle's sides, t1 <= ty <= t2 holds in floats, tmin = tmax = ty, and "tmax >= tmin && tmax > 0"
+    // (aabb.c:55) is "ty > 0".
+    static bool inside_for_certain(const uint32_t* rec, const int* ax, const double* rlo, const double* rhi, const double* gate) {
+        for (int j = 0; j < 2; j++) {
+            const double bmin = bits_as_float(rec[ax[j]]), bmax = bits_as_float(rec[3 + ax[j]]);
+            if (!(rlo[j] >= bmin + gate[j] && rhi[j] <= bmax - gate[j])) return false;
+        }
+        return true;
+    }
+
     // A mesh whose root box has zero thickness along one axis k (a ground plane) is met by a ray in ONE point X of its plane,
     // and a leaf's slab test can only pass if X lies in the leaf's rectangle, up to rounding: with all direction
     // components finite and non-zero, "tmax >= tmin" needs the plane's parameter ty to lie between the two parameters of
@@ -528,12 +603,11 @@ private:
             lo[j] = out_.root_min[ax[j]]; ext[j] = (double)out_.root_max[ax[j]] - lo[j];
             if (!(ext[j] > 0) || !(ext[j] < 1e30)) return;
         }
-        // cells well below the size of a leaf's rectangle, so that most cells lie inside one leaf (or two): eight per side
-        // and leaf on average
-        int n = (int)ceil(sqrt(64.0 * (double)(leaves_.empty() ? out_.tree_pairs : leaves_.size())));
+        // cells well below the size of a triangle, so that most cells lie inside one: eight per side and triangle on average
+        int n = (int)ceil(sqrt(64.0 * (double)(out_.tris.empty() ? (size_t)out_.tree_pairs : out_.tris.size())));
         n = n < 8 ? 8 : (n > 256 ? 256 : n);
         double cs[2], slack[2];
-        for (int j = 0; j < 2; j++) { cs[j] = ext[j] / n; slack[j] = cs[j] / 8.0; }
+        for (int j = 0; j < 2; j++) { cs[j] = ext[j] / n; slack[j] = cs[j] / kGridSlackShare; }
         out_.grid.assign((size_t)n * (size_t)n, leaf_ref(0, 0));
         auto overlaps = [&](const float* bmin, const float* bmax, const double* rlo, const double* rhi) {
             for (int j = 0; j < 2; j++)
@@ -554,24 +628,27 @@ private:
                 }
                 out_.grid[(size_t)iy * (size_t)n + (size_t)ix] = ref;
             }
-        // Where the walk would start at a node (several leaves' boxes overlap the padded cell, which is the rule for the
-        // overlapping leaves the reference's mean split leaves), the cell names those leaves themselves instead: a list of up to
-        // kGridListMax records {leaf box, leaf reference} behind the cells.  A ray whose X lies in the cell can pass no other
-        // leaf's box, and a leaf is reached exactly when its own box is passed (ancestors' boxes contain it), so testing the
-        // listed boxes one by one reaches the leaves the walk would reach -- without the boxes above them.
+        // What a cell finally names is a list of up to kGridListMax records {leaf box, leaf reference, triangle mask}: the
+        // leaves whose boxes overlap the padded cell -- a ray whose X lies in the cell can pass no other leaf's box, and a leaf
+        // is reached exactly when its own box is passed (ancestors' boxes contain it), so testing the listed boxes one by one
+        // reaches the leaves the walk would reach, without the boxes above them -- and, per leaf, the triangles that such a
+        // ray can possibly be accepted by (tri_mask below); a leaf none of whose triangles qualifies is left out.  Only where
+        // more leaves than fit overlap the cell does the walk start at the node found above.  Equal lists are stored once.
         const size_t cells = (size_t)n * (size_t)n, list_base = (cells + 7) & ~(size_t)7;
         out_.grid.resize(list_base, leaf_ref(0, 0));
-        std::vector<uint32_t> stack;
+        const double gate[2] = {slack[0] * 0.5, slack[1] * 0.5};
+        std::map<std::vector<uint32_t>, uint32_t> known;
+        std::vector<uint32_t> stack, list;
         for (int iy = 0; iy < n; iy++)
             for (int ix = 0; ix < n; ix++) {
-                const uint32_t entry = out_.grid[(size_t)iy * (size_t)n + (size_t)ix];
-                if (entry & kLeafBit) continue;
+                const size_t ci = (size_t)iy * (size_t)n + (size_t)ix;          // (the vector grows below: no reference into it)
+                if (out_.grid[ci] == leaf_ref(0, 0)) continue;                              // no leaf's box overlaps the padded cell
                 const double rlo[2] = {lo[0] + ix * cs[0] - slack[0], lo[1] + iy * cs[1] - slack[1]};
                 const double rhi[2] = {lo[0] + (ix + 1) * cs[0] + slack[0], lo[1] + (iy + 1) * cs[1] + slack[1]};
-                uint32_t rec[kGridListMax][8];
+                list.clear();
                 uint32_t count = 0;
                 bool fits = true;
-                stack.assign(1, entry);
+                stack.assign(1, out_.root_ref);
                 while (!stack.empty() && fits) {
                     const PairNode& N = out_.pairs[stack.back()];
                     stack.pop_back();
@@ -581,18 +658,41 @@ private:
                         const uint32_t child = side ? N.rref : N.lref;
                         if (!overlaps(bmin, bmax, rlo, rhi)) continue;
                         if (!(child & kLeafBit)) { stack.push_back(child); continue; }
-                        if (((child >> 24) & 0x7Fu) == 0) continue;
+                        const uint32_t mask = tri_mask(child, k, ax, rlo, rhi, gate);
+                        if (mask == 0) continue;
                         if (count == kGridListMax) { fits = false; break; }
-                        memcpy(&rec[count][0], bmin, 12); memcpy(&rec[count][3], bmax, 12);
-                        rec[count][6] = child; rec[count][7] = 0;
+                        uint32_t rec[8];
+                        memcpy(&rec[0], bmin, 12); memcpy(&rec[3], bmax, 12);
+                        rec[6] = child; rec[7] = mask;
+                        list.insert(list.end(), rec, rec + 8);
                         count++;
                     }
                 }
-                const size_t at = (out_.grid.size() - list_base) / 8;
-                if (!fits || at + count > 0x00FFFFFFu) continue;                 // too many leaves: the walk starts at the node as before
-                if (count == 0) { out_.grid[(size_t)iy * (size_t)n + (size_t)ix] = leaf_ref(0, 0); continue; }
-                for (uint32_t c = 0; c < count; c++) out_.grid.insert(out_.grid.end(), &rec[c][0], &rec[c][0] + 8);
-                out_.grid[(size_t)iy * (size_t)n + (size_t)ix] = kGridListBit | (count << 24) | (uint32_t)at;
+                if (!fits) {                                                       // too many leaves: the walk starts at a node, as found above
+                    if (out_.grid[ci] & kLeafBit) out_.grid[ci] = out_.root_ref;                     // (never a leaf by itself: a leaf's own box must be tested)
+                    continue;
+                }
+                if (count == 0) { out_.grid[ci] = leaf_ref(0, 0); continue; }
+                // One leaf, one triangle, and the padded cell well inside the leaf's rectangle: a ray through the cell passes the
+                // leaf's box exactly when it meets the plane in front of its origin (inside_for_certain), so the cell names the
+                // triangle itself and the walk tests that distance instead of the box.
+                if (count == 1 && (list[7] & (list[7] - 1u)) == 0u && ((list[6] >> 24) & 0x7Fu) <= 32u && inside_for_certain(&list[0], ax, rlo, rhi, gate)) {
+                    uint32_t bit = 0;
+                    while (!((list[7] >> bit) & 1u)) bit++;
+                    out_.grid[ci] = leaf_ref((list[6] & 0x00FFFFFFu) + bit, 1u);
+                    continue;
+                }
+                auto seen = known.find(list);
+                uint32_t at;
+                if (seen != known.end()) {
+                    at = seen->second;
+                } else {
+                    at = (uint32_t)((out_.grid.size() - list_base) / 8);
+                    if ((size_t)at + count > 0x00FFFFFFu) { if (out_.grid[ci] & kLeafBit) out_.grid[ci] = out_.root_ref; continue; }
+                    out_.grid.insert(out_.grid.end(), list.begin(), list.end());
+                    known.emplace(list, at);
+                }
+                out_.grid[ci] = kGridListBit | (count << 24) | at;
             }
         out_.grid_axis = (uint32_t)k; out_.grid_n = n;
         for (int j = 0; j < 2; j++) {

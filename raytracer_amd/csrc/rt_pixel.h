@@ -228,11 +228,14 @@ struct Query {
 // Tests the triangles of one leaf (bvh.c:89-103).  Returns true when an any-hit query may stop.
 // Triangles are fetched LB at a time before any of them is tested (one memory round trip per batch, at ten registers per
 // triangle held).
+// `mask` (leaves of at most 32 triangles): only the triangles whose bit is set -- the others are known to reject this ray
+// (the lists of a flat mesh's grid, Packer::tri_mask).
 template <bool ANY, bool COUNT, bool FULL, uint32_t LB, class Nodes>
-RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, F3 d, Query& q, Work& work) {
+RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, F3 d, Query& q, Work& work, const uint32_t mask = 0xFFFFFFFFu) {
     constexpr bool CULL = !FULL && !ANY;
     const uint32_t first = ref & 0x00FFFFFFu, count = (ref >> 24) & 0x7Fu;
     for (uint32_t i0 = 0; i0 < count; i0 += LB) {
+        if (LB == 1 && mask != 0xFFFFFFFFu && !((mask >> (i0 & 31u)) & 1u)) continue;
         TriRec T[LB];                                          // registers: every index below is a constant
         const uint32_t n = count - i0 < LB ? count - i0 : LB;
         RT_UNROLL
@@ -240,6 +243,7 @@ RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, 
         RT_UNROLL
         for (uint32_t k = 0; k < LB; k++) {
             if (k >= n) continue;
+            if (LB > 1 && mask != 0xFFFFFFFFu && !((mask >> ((i0 + k) & 31u)) & 1u)) continue;
             float t, u, v;
             if (COUNT) work.tris++;
             if (!moller_trumbore(o, d, f3(T[k].v0), f3(T[k].e1), f3(T[k].e2), t, u, v)) continue;
@@ -298,9 +302,10 @@ RT_HD float comp(F3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.
 // that holds the point X in which the ray meets the mesh's plane -- if the ray qualifies: all direction components finite
 // and non-zero (the caller checks the zeros), X inside the grid, and the ray's own uncertainty about X (16 u of the
 // magnitudes that enter it) no more than the slack the cells were built with.  Otherwise the tree's root.
-RT_HD uint32_t grid_entry(const MeshArgs& M, F3 o, F3 d, F3 inv, uint32_t root) {
+RT_HD uint32_t grid_entry(const MeshArgs& M, F3 o, F3 d, F3 inv, uint32_t root, float& plane_t) {
     const uint32_t k = M.grid_axis, a = k == 2 ? 0u : k + 1u, b = k == 0 ? 2u : (k == 1 ? 0u : 1u);
     const float ty = (M.root_min[k] - comp(o, k)) * comp(inv, k);              // aabb.c:39-53 for the flat axis
+    plane_t = ty;
     const float sa = ty * comp(d, a), sb = ty * comp(d, b);
     const float xa = comp(o, a) + sa, xb = comp(o, b) + sb;
     const float ea = (fabsf(comp(o, a)) + fabsf(sa) + M.grid_bmax[0]) * 9.5367431640625e-7f;      // 2^-20 = 16 u
@@ -334,7 +339,16 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
         // nothing but triangle tests, so the lanes of a wave do not drag each other through both
         // kinds of work on every step.
         uint32_t ref = entry_ref<false>(M, d);
-        if (use_grid && M.grid_axis < 3u && ref == M.root_ref && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) ref = grid_entry(M, o, d, inv, ref);
+        if (use_grid && M.grid_axis < 3u && ref == M.root_ref && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) {
+            float plane_t = 0.0f;
+            ref = grid_entry(M, o, d, inv, ref, plane_t);
+            if (ref & kLeafBit) {
+                // the cell names one triangle (or nothing): the ray passes its leaf's box exactly when it meets the mesh's plane in
+                // front of its origin (Packer::inside_for_certain), so that is tested in the box test's place
+                if (COUNT) work.slabs++;
+                if (!(plane_t > 0.0f) || (CULL && plane_t > q.limit)) return false;
+            }
+        }
         if (!(ref & kLeafBit) && (ref & kGridListBit)) {
             // the cell names its leaves: each one's own box test (the reference reaches a leaf exactly when that passes,
             // the boxes above contain it), nothing else
@@ -343,14 +357,20 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
             for (uint32_t i = 0; i < count; i++) {
                 float bmin[3], bmax[3];
                 const size_t at = first + (size_t)i * 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+                const f32x4 r0 = global_read<f32x4>(M.grid, at * 4), r1 = global_read<f32x4>(M.grid, at * 4 + 16);     // records are 32-byte aligned
+                bmin[0] = r0.x; bmin[1] = r0.y; bmin[2] = r0.z; bmax[0] = r0.w; bmax[1] = r1.x; bmax[2] = r1.y;
+                const uint32_t leaf = f32_as_uint(r1.z), mask = f32_as_uint(r1.w);
+#else
                 RT_UNROLL
                 for (int c = 0; c < 3; c++) { bmin[c] = uint_as_f32(read_word(M.grid, at + c)); bmax[c] = uint_as_f32(read_word(M.grid, at + 3 + c)); }
-                const uint32_t leaf = read_word(M.grid, at + 6);
+                const uint32_t leaf = read_word(M.grid, at + 6), mask = read_word(M.grid, at + 7);
+#endif
                 if (COUNT) work.slabs++;
                 float entry;
                 if (!slab_t(o, inv, bmin, bmax, entry)) continue;
                 if (CULL && entry > q.limit) continue;
-                if (test_leaf<ANY, COUNT, FULL, LB>(M, nodes, leaf, o, d, q, work)) return true;
+                if (test_leaf<ANY, COUNT, FULL, LB>(M, nodes, leaf, o, d, q, work, mask)) return true;
             }
             hit = q.hit;
             return q.found;

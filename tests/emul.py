@@ -82,6 +82,7 @@ def lib():
         L.emul_set_vis_shrink.argtypes = [vp, i32]
         L.emul_set_vis_shrink.restype = None
         L.emul_damage_grid.argtypes = [vp, i32]
+        L.emul_damage_grid_masks.argtypes = [vp, i32]
         L.emul_damage_second_tree.argtypes = [vp, i32]
         _lib = L
     return _lib
@@ -220,6 +221,9 @@ class Scene:
 
     def damage_grid(self, mesh: int) -> int:
         return lib().emul_damage_grid(self.h, int(mesh))
+
+    def damage_grid_masks(self, mesh: int) -> int:
+        return lib().emul_damage_grid_masks(self.h, int(mesh))
 
     def damage_second_tree(self, mesh: int) -> int:
         return lib().emul_damage_second_tree(self.h, int(mesh))

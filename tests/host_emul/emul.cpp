@@ -82,6 +82,20 @@ int emul_damage_grid(void* sp, int mesh) {
     for (size_t i = 0; i < cells && i < pk.grid.size(); i++) pk.grid[i] = leaf;
     return RT_OK;
 }
+// The same grid with its triangle selection broken: every listed leaf keeps only its first triangle, and every cell that
+// names a single triangle names the one after it.
+int emul_damage_grid_masks(void* sp, int mesh) {
+    EmulScene* s = (EmulScene*)sp;
+    if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;
+    PackedMesh& pk = s->meshes[(size_t)mesh].pk;
+    if (pk.grid_axis >= 3 || pk.grid.empty()) return RT_ERR_UNSUPPORTED;
+    const size_t cells = (size_t)pk.grid_n * (size_t)pk.grid_n, list_base = (cells + 7) & ~(size_t)7;
+    int changed = 0;
+    for (size_t i = 0; i < cells; i++)
+        if ((pk.grid[i] & kLeafBit) && ((pk.grid[i] >> 24) & 0x7Fu) == 1u) { pk.grid[i] = leaf_ref(((pk.grid[i] & 0x00FFFFFFu) + 1u) % (uint32_t)pk.tris.size(), 1u); changed++; }
+    for (size_t r = list_base; r + 8 <= pk.grid.size(); r += 8) { if (pk.grid[r + 7] != 1u) changed++; pk.grid[r + 7] = 1u; }
+    return changed > 0 ? RT_OK : RT_ERR_UNSUPPORTED;
+}
 int emul_damage_second_tree(void* sp, int mesh) {
     EmulScene* s = (EmulScene*)sp;
     if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;

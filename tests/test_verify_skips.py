@@ -173,6 +173,13 @@ def test_damaged_shortcuts_are_noticed(po, meshes):
     c = s.render(cam, light, tfs, 240, 135, verify=True)["counters"]
     assert c["cull_disagreements"] > 100 and c["entry_disagreements"] == 0, c
     s.close()
+    s = emul.Scene(regroup=True)
+    for m in meshes:
+        assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+    assert s.damage_grid_masks(2) == 0                # the ground's cells name the wrong triangles
+    c = s.render(cam, light, tfs, 240, 135, verify=True)["counters"]
+    assert c["entry_disagreements"] > 1000 and c["cull_disagreements"] == 0 and c["vis_disagreements"] == 0, c
+    s.close()
 
 
 # ------------------------------------------------------------------------------------------ GPU: through the C ABI
