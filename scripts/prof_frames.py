@@ -61,6 +61,9 @@ def main():
     p.add_argument("--mode", default="frames", choices=["frames", "bench", "sampled", "instanced", "upscale"],
                    help="bench: the launches of bench.py's timed region (96 steps, bench.FRAMES_PER_LAUNCH frames per launch); sampled: 4K/16 samples/2 lights; instanced: 56x56 treasures; upscale: 16 frames 1080p -> scale 0.9")
     p.add_argument("--wave", type=int, default=-1, help="option instanced_wave (instanced mode)")
+    p.add_argument("--count-packed", action="store_true",
+                   help="bench mode: no launches for the counters; prints the two-wide packed float operations per launch as the kernel's own "
+                        "work counters see them (six per box test), the fifth argument of scripts/pmc_to_profile.py")
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     a = p.parse_args()
@@ -79,6 +82,17 @@ def main():
         seq = bench.frame_sequence(list(range(demo.N_FRAMES)), 96)
         n = bench.FRAMES_PER_LAUNCH
         buf = torch.empty((n, a.height, a.width, 3), dtype=torch.uint8, device=dev)
+        if a.count_packed:
+            from raytracer_amd import capi
+            boxes = {}
+            for f in sorted(set(seq)):
+                scene.render(f, a.width, a.height, buf[0], flags=capi.RT_FLAG_COUNT_WORK)
+                scene.ctx.sync()
+                boxes[f] = scene.ctx.last_counters()["slab_tests"]
+            per_launch = [sum(boxes[f] for f in seq[b:b + n]) for b in range(0, 96, n)]
+            print(int(6 * sum(per_launch) / len(per_launch)))
+            scene.close()
+            return
         for _ in range(a.repeat):
             for b in range(0, 96, n):
                 scene.render_frames(seq[b:b + n], a.width, a.height, buf)
