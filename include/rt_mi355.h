@@ -346,10 +346,14 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * 1, default = the hierarchy over the instances is kept between calls and patched while few instances change
  * their place; 0 = built anew for every call), "fast" (0, default = the exact build of the kernels: every float
  * operation of the reference once, in its order, no fused multiply-adds, correctly rounded division and square root --
- * all outputs bit-identical to the reference; 1 = the fast build for rt_render_frame, rt_render_frame_strips and
- * rt_render_frames: contraction on, hardware reciprocal / reciprocal square root, the slab test as one fused multiply-add per
- * bound.  Not bit-exact: hit ids equal on at least 99.99 % of camera rays and 8-bit colours within 1 on at least 99.9 % of
- * pixels against the exact build, which the GPU tests assert; measured about 6 % faster), "instanced_wave" (rt_render_frame_instanced: 0, default = one lane per pixel walks
+ * all outputs bit-identical to the reference; 1 = the fast build for rt_render_frame, rt_render_frame_strips,
+ * rt_render_frames and rt_render_frame_instanced: contraction on, hardware reciprocal / reciprocal square root, the slab test
+ * as one fused multiply-add per bound, and closed meshes walked through a tree over their triangles themselves (leaves of up
+ * to eight neighbouring triangles in tight boxes, built beside the other trees at upload when option "regroup" is on) instead
+ * of the reference's leaves.  Not bit-exact: hit ids equal on at least 99.99 % of camera rays and 8-bit colours within 1 on at
+ * least 99.9 % of pixels against the exact build, which the GPU tests assert; measured 1.3-1.4 times as fast on the animation,
+ * 1.5 times on the instanced stress scene.  Calls with RT_FLAG_VERIFY_SKIPS or RT_FLAG_REFERENCE_ORDER run the exact build
+ * whatever this option says; rt_render_frame_sampled always does), "instanced_wave" (rt_render_frame_instanced: 0, default = one lane per pixel walks
  * hierarchy, instance and triangles as nested loops; 1..8 = every lane is a state machine and the wave executes the step most of
  * its lanes wait for, lanes taking new pixels from a strip of that many tiles -- more lanes busy per instruction, more
  * instructions: measured slower, kept for comparison).
