@@ -43,6 +43,7 @@ struct DeviceMesh {
     // records; the ordinary entry and no copy where there is none
     uint32_t loose_root = kLeafBit, loose_pairs = 0;
     TriRec* d_loose_tris = nullptr;
+    size_t n_loose_tris = 0;
 };
 
 }  // namespace
@@ -214,11 +215,21 @@ int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tr
     dm.proto.root_ref = pk.root_ref; dm.proto.ref_root = pk.ref_root;
     dm.proto.empty = pk.empty ? 1u : 0u;
     dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.tree_pairs;
-    if (dm.d_loose_tris) { (void)hipFree(dm.d_loose_tris); dm.d_loose_tris = nullptr; }
     dm.loose_root = pk.root_ref; dm.loose_pairs = pk.tree_pairs;
-    if (!pk.loose_tris.empty()) {
-        const int lst = upload_array(ctx, pk.loose_tris, &dm.d_loose_tris);
-        if (lst != RT_OK) return lst;
+    if (pk.loose_tris.empty()) {
+        if (dm.d_loose_tris) { (void)hipFree(dm.d_loose_tris); dm.d_loose_tris = nullptr; }
+        dm.n_loose_tris = 0;
+    } else {
+        if (dm.d_loose_tris && dm.n_loose_tris == pk.loose_tris.size()) {      // a mesh rebuilt every frame keeps its array
+            RT_HIP(ctx, hipMemcpy(dm.d_loose_tris, pk.loose_tris.data(), pk.loose_tris.size() * sizeof(TriRec), hipMemcpyHostToDevice));
+        } else {
+            TriRec* fresh = nullptr;
+            const int lst = upload_array(ctx, pk.loose_tris, &fresh);
+            if (lst != RT_OK) { if (fresh) (void)hipFree(fresh); return lst; }
+            if (dm.d_loose_tris) (void)hipFree(dm.d_loose_tris);
+            dm.d_loose_tris = fresh;
+            dm.n_loose_tris = pk.loose_tris.size();
+        }
         dm.loose_root = pk.loose_root; dm.loose_pairs = pk.loose_pairs;
     }
     return RT_OK;
@@ -266,6 +277,7 @@ int build_into(rt_ctx* ctx, DeviceMesh& dm, const rt_triangle* tris, int32_t n, 
                 dm.depth = both.depth; dm.n_pairs = (int32_t)both.tree_pairs;
             }
             if (dm.d_loose_tris) { (void)hipFree(dm.d_loose_tris); dm.d_loose_tris = nullptr; }
+            dm.n_loose_tris = 0;
             dm.loose_root = dm.proto.root_ref; dm.loose_pairs = (uint32_t)dm.n_pairs;
             return RT_OK;
         }
