@@ -214,6 +214,7 @@ int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tr
     memcpy(dm.proto.root_max, pk.root_max, 12);
     dm.proto.root_ref = pk.root_ref; dm.proto.ref_root = pk.ref_root;
     dm.proto.empty = pk.empty ? 1u : 0u;
+    dm.proto.wide = pk.wide ? 1u : 0u;
     dm.n_tris = n_tris; dm.n_pairs = (int32_t)pk.tree_pairs;
     dm.loose_root = pk.root_ref; dm.loose_pairs = pk.tree_pairs;
     if (pk.loose_tris.empty()) {
@@ -262,6 +263,7 @@ int build_into(rt_ctx* ctx, DeviceMesh& dm, const rt_triangle* tris, int32_t n, 
             memcpy(dm.proto.root_max, pk.root_max, 12);
             dm.proto.root_ref = pk.root_ref; dm.proto.ref_root = pk.root_ref;
             dm.proto.empty = 0u;
+            dm.proto.wide = any_wide_triangle(tris, n) ? 1u : 0u;
             dm.n_tris = n; dm.n_pairs = (int32_t)dm.pairs.size();
             if (ctx->regroup) {
                 // the nodes are on the host anyway: the surface-area-split tree over the same leaves is built here (0.4 s for

@@ -73,7 +73,7 @@ RT_HD void take_walk_fields(const MeshArgs& M, MeshArgs& W) {
     W.pair_base = M.pair_base; W.tris = M.tris;
     W.root_min[0] = M.root_min[0]; W.root_min[1] = M.root_min[1]; W.root_min[2] = M.root_min[2];
     W.root_max[0] = M.root_max[0]; W.root_max[1] = M.root_max[1]; W.root_max[2] = M.root_max[2];
-    W.root_ref = M.root_ref; W.ref_root = M.ref_root; W.empty = M.empty;
+    W.root_ref = M.root_ref; W.ref_root = M.ref_root; W.empty = M.empty; W.wide = M.wide;
     W.res_pairs = kNotResident; W.res_tris = kNotResident;
     W.grid = nullptr; W.grid_axis = 3u;
 }
@@ -112,7 +112,7 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
             // a single leaf honours the bound inside the leaf (bvh.c:85): it gets none, the comparison below decides
             float entry;
             if (!slab_t(lo, linv, W.root_min, W.root_max, entry) || W.empty) return false;
-            return !(entry > cull_limit((W.root_ref & kLeafBit) ? 1e30f : closest));
+            return W.wide || !(entry > cull_limit((W.root_ref & kLeafBit) ? 1e30f : closest));
         });
         if (i < 0) break;
         Hit h = no_hit();

@@ -91,6 +91,7 @@ __device__ __forceinline__ void start_pixel(WaveLane<BLOCK>& L, const FrameArgs&
 }
 
 // One box pair: both children's slab tests, nearer child first, the farther one parked (trace_mesh's inner step).
+// (This form keeps the distance cull inside every instance, MeshArgs::wide or not: it is the comparison variant, not the default.)
 template <int BLOCK>
 __device__ __forceinline__ void step_box(WaveLane<BLOCK>& L) {
     const PairNode N = L.base[L.ref];

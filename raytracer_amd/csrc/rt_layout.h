@@ -70,6 +70,9 @@ struct MeshArgs {
     uint32_t root_ref;           // leaf_ref(...) or PairNode index 0
     int32_t tex_w, tex_h;
     uint32_t empty;              // 1: mesh has no triangles (root box never leads to a hit)
+    uint32_t wide;               // 1: the mesh holds a triangle large enough for ray.c:50's cut-off |a| < 1e-7 to admit rays that run almost
+                                 // inside its plane, where ray.c:63's distance can come out far in front of the surface: nothing
+                                 // of such a mesh is skipped for being farther away than the closest hit (Packer: kWideTriangle)
     float inv[3][4];             // rows 0..2 of inverse(T*Rz*Ry*Rx)
     float wrow[4];               // row 3 of the same matrix (mat4_transform_point divides by it)
     float nrm[3][3];             // upper 3x3 of transpose(inverse(Rz*Ry*Rx))

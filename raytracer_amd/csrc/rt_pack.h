@@ -28,6 +28,24 @@ static_assert(sizeof(rt_transform) == 24 && sizeof(rt_camera) == 40 && sizeof(rt
 inline F3 f3(const rt_vec3& v) { return f3(v.x, v.y, v.z); }
 inline float bits_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+// MeshArgs::wide.  The triangle test's distance t = (e2 . (s x e1)) / a (ray.c:47-63) is off by about 8 u |e1| |e2| |s| / |a|
+// (u = 2^-24), and the only rays it turns away are those with |a| = |e1 x e2| |cos| < 1e-7 (ray.c:50): the larger the triangle,
+// the closer to its plane a ray may run and still be tested, and the farther off t -- and with it u, v, so that rays which
+// miss the triangle are accepted as well.  For the reference scene's drone (rotor discs of 2.8 x 2.8) such hits came out 8 %
+// in front of the plane; the distance cull's margin is 0.2 %.  Three rays in 3.6e10 of a self-checking run were affected, all
+// on those triangles.  Triangles below the threshold can misbehave in the same way only within a far narrower band of
+// directions and over an area hundreds of times smaller.
+constexpr float kWideTriangle = 0.25f;
+inline bool wide_triangle(const rt_triangle& t) {
+    const float a[3] = {t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z}, b[3] = {t.v2.x - t.v0.x, t.v2.y - t.v0.y, t.v2.z - t.v0.z};
+    const double k2 = ((double)a[0] * a[0] + (double)a[1] * a[1] + (double)a[2] * a[2]) * ((double)b[0] * b[0] + (double)b[1] * b[1] + (double)b[2] * b[2]);
+    return !(k2 < (double)kWideTriangle * (double)kWideTriangle);      // a NaN counts as wide
+}
+inline bool any_wide_triangle(const rt_triangle* tris, int32_t n) {
+    for (int32_t i = 0; i < n; i++) if (wide_triangle(tris[i])) return true;
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------
 // Reference builder (accel/bvh.c:4-59).  The tree is produced in creation order
 // (node, left subtree, right subtree) and the triangle array is permuted in place.
@@ -122,6 +140,7 @@ struct PackedMesh {
     // Without one both are the same.  tree_pairs = nodes of the tree root_ref enters.
     uint32_t ref_root = kLeafBit;
     uint32_t tree_pairs = 0;
+    bool wide = false;                // a triangle with |e1| |e2| >= kWideTriangle (MeshArgs::wide)
     // FlatGrid (see Packer::build_grid): entry references per cell, row-major [second in-plane axis][first]; axis 3 = none
     std::vector<uint32_t> grid;
     uint32_t grid_axis = 3;
@@ -170,6 +189,7 @@ public:
             a.n2[0] = s.n2.x; a.n2[1] = s.n2.y; a.n2[2] = s.n2.z;
             a.pad = 0;
         }
+        out_.wide = any_wide_triangle(tris_, n_tris_);
         if (n_nodes_ == 0) return RT_OK;                         // nothing to traverse
         covered_.assign((size_t)n_tris_, 0);
         visited_.assign((size_t)n_nodes_, 0);

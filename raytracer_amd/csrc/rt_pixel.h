@@ -145,6 +145,11 @@ template <> struct ScalarNodes<GlobalNodes> { static constexpr bool on = true; _
 // best*(1 + 2^-9) + 2^-13: a triangle inside it would need a t that is wrong by 0.2 % to have won.
 // Ties (equal t) lie well inside the margin and are still visited, so the tie rule is unaffected.
 RT_HD float cull_limit(float best) { return best * 1.001953125f + 0.0001220703125f; }
+// The limit of a query that skips nothing by distance (MeshArgs::wide): the margin above covers a triangle test whose distance
+// is off by up to 0.2 %.  That holds for rays that meet a triangle's plane at more than about 2e-4 rad; ray.c:50 only turns away
+// rays with |a| < 1e-7, and for a triangle with edges of 0.5 or more |a| = 2 area |cos| stays above that down to 1e-6 rad and
+// less, where the computed distance (and u, v) are off by percents.  The reference accepts such a hit wherever it falls.
+constexpr float kNoCull = 3.0e38f;
 
 // True when hit a (if found) is the one the reference would keep over hit b.
 RT_HD bool beats(bool a_found, const Hit& a, bool b_found, const Hit& b) {
@@ -260,7 +265,7 @@ RT_HD bool test_leaf(const MeshArgs& M, const Nodes& nodes, uint32_t ref, F3 o, 
 #else
                 q.hit.tri = first + i0 + k;
 #endif
-                if (CULL && t < q.bound) q.limit = cull_limit(t);
+                if (CULL && t < q.bound && q.limit < kNoCull) q.limit = cull_limit(t);
             }
         }
     }
@@ -281,7 +286,7 @@ RT_HD bool begin_query(const MeshArgs& M, F3 o, F3 inv, float bound, Query& q, W
     // result only if it is below `bound` (scene.c:82), so hits at or beyond it need not be found.
     q.best_t = (M.root_ref & kLeafBit) ? bound : 1e30f;
     q.bound = bound;
-    q.limit = cull_limit(bound);
+    q.limit = M.wide ? kNoCull : cull_limit(bound);
     q.found = false;
     q.hit = no_hit();
     return !(CULL && entry > q.limit);

@@ -340,6 +340,22 @@ def verify_skips(a):
     tex = rng.integers(0, 256, size=(8, 8, 4), dtype=np.uint8)
     pixels = checks = 0
     per_kind = {"plain": 0, "soups": 0, "lists": 0}
+    # The distance cull is the one shortcut that rests on a stated condition instead of a bound (a culled box can hold a triangle
+    # that the ray grazes and whose computed distance is wrong by more than the margin): its disagreements are recorded and counted
+    # and the run goes on.  Any other disagreement, or a flagged frame that differs from the plain one, ends the run.
+    cull_rays, cull_findings = 0, []
+
+    def judge(record, bad, same):
+        nonlocal cull_rays
+        hard = {n: v for n, v in bad.items() if n != "cull_disagreements"}
+        if hard or not same:
+            print(json.dumps(record))
+            sys.exit(1)
+        if bad:
+            cull_rays += bad["cull_disagreements"]
+            if len(cull_findings) < 20:
+                cull_findings.append(record)
+            print(json.dumps(record), file=sys.stderr, flush=True)
 
     def wild(values):
         return tuple(float(rng.choice(special)) if rng.uniform() < a.wild else float(v) for v in values)
@@ -372,8 +388,7 @@ def verify_skips(a):
         same = all(np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y) for x, y in zip(a_, b_))
         bad = {n: cnt[n] for n in kinds if cnt[n]}
         if bad or not same:
-            print(json.dumps({"scene": k, "seed": a.seed, "kind": what, "size": [w, h], "disagreements": bad, "planes_equal": same, **describe(cam, light, tfs)}))
-            sys.exit(1)
+            judge({"scene": k, "seed": a.seed, "kind": what, "size": [w, h], "disagreements": bad, "planes_equal": same, **describe(cam, light, tfs)}, bad, same)
         pixels += w * h
         checks += cnt["skip_checks"]
 
@@ -433,17 +448,17 @@ def verify_skips(a):
             same = all(torch.equal(x, y) for x, y in zip(*planes))
             bad = {nm: cnt[nm] for nm in kinds if cnt[nm]}
             if bad or not same:
-                print(json.dumps({"scene": k, "seed": a.seed, "kind": "lists", "size": [w, h], "ids": ids, "disagreements": bad, "planes_equal": same,
-                                  **describe(cam, light, tfs)}))
-                sys.exit(1)
+                judge({"scene": k, "seed": a.seed, "kind": "lists", "size": [w, h], "ids": ids, "disagreements": bad, "planes_equal": same,
+                       **describe(cam, light, tfs)}, bad, same)
             pixels += w * h
             checks += cnt["skip_checks"]
             per_kind["lists"] += 1
         if (k + 1) % 100 == 0:
-            print(f"[soak] {k + 1} scenes checked themselves: no disagreement", file=sys.stderr, flush=True)
+            print(f"[soak] {k + 1} scenes checked themselves: {cull_rays} rays where the distance cull changed the outcome, no other disagreement", file=sys.stderr, flush=True)
     print(json.dumps({"scenes": a.scenes, "seed": a.seed, "mode": "RT_FLAG_VERIFY_SKIPS: shortcuts against the reference's way, on the device, ray by ray",
-                      "scenes_by_kind": per_kind, "pixels": pixels, "decisions_examined": checks, "disagreements": 0,
-                      "planes_equal_to_the_unflagged_frame": True, "wild": a.wild}))
+                      "scenes_by_kind": per_kind, "pixels": pixels, "decisions_examined": checks,
+                      "disagreements": {"vis": 0, "shadow_vis": 0, "entry": 0, "instance": 0, "cull": cull_rays},
+                      "cull_findings": cull_findings, "planes_equal_to_the_unflagged_frame": True, "wild": a.wild}))
     ctx.close()
 
 

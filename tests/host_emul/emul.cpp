@@ -204,7 +204,7 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
         M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root;
         if (s->loose && !E.pk.loose_tris.empty()) { M.root_ref = M.ref_root = E.pk.loose_root; M.tris = E.pk.loose_tris.data(); }
-        set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u; M.wide = E.pk.wide ? 1u : 0u;
         fill_placement(tfs[m], A, M);
         mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
     }
@@ -282,7 +282,7 @@ int emul_render_sampled(void* sp, const rt_camera* cam, const rt_light* lights, 
         M.pair_base = base; M.pair_count = E.pk.tree_pairs; base += (uint32_t)E.pk.pairs.size();
         M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
-        M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u; M.wide = E.pk.wide ? 1u : 0u;
         fill_placement(tfs[m], A, M);
         mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
     }
@@ -344,7 +344,7 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
         M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root;
         if (s->loose && !E.pk.loose_tris.empty()) { M.root_ref = M.ref_root = E.pk.loose_root; M.tris = E.pk.loose_tris.data(); }
-        set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u;
+        set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u; M.wide = E.pk.wide ? 1u : 0u;
         fill_placement(tfs[i], A, M);
         if (!M.empty) { boxes.push_back(instance_box(tfs[i], M.root_min, M.root_max)); ids.push_back((uint32_t)i); }
     }

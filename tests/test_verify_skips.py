@@ -356,3 +356,44 @@ def test_gpu_thousands_of_entries_check_their_hierarchy(capi, gctx, po, meshes):
     got = gpu_instanced_checked(capi, gctx, po, ids, tfs, po.default_camera(), po.default_light(), w, h)
     check_instanced(got, fr, inst, tri)
     assert_clean(got["counters"], "3 138 entries", min_checks=w * h)
+
+
+# What the long self-checking runs found on tame input (tests/golden/cull_findings.json: three scenes of 90 000, one ray each):
+# the driver's meshes under random placements, the camera close to the drone.  In the first, the ray of pixel (596, 127) runs
+# within 2e-4 rad of the plane of one of the drone's 2.8-unit rotor triangles and misses the triangle (v = -0.07 in double
+# precision); the reference's float triangle test (ray.c:42-67), with a = -2.9e-6, lets it pass with t = 1.6667, 8 % off the
+# plane's true distance of 1.811 -- in front of the real surface at 1.7067, which the ordered walk had found by then, so that it
+# dropped the rotor's box (entered beyond 1.71) unvisited.  The other two are the same triangles under other views.  Since then
+# nothing of a mesh with such triangles is skipped by distance (MeshArgs::wide), and these scenes are the regression test.
+def cull_finding_scenes(po):
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cull_findings.json")) as f:
+        records = json.load(f)
+    f32 = lambda v: float(np.float32(float(v)))
+    for r in records:
+        c = [f32(v) for v in r["camera"]]
+        l = [f32(v) for v in r["light"]]
+        cam = po.Camera(po.vec3(*c[0:3]), po.vec3(*c[3:6]), po.vec3(*c[6:9]), c[9])
+        light = po.Light(po.vec3(*l[0:3]), po.vec3(*l[3:6]))
+        tfs = [po.Transform(po.vec3(*[f32(v) for v in p[0:3]]), po.vec3(*[f32(v) for v in p[3:6]])) for p in r["placements"]]
+        yield f"scene {r['scene']} of seed {r['seed']}", cam, light, tfs, tuple(r["size"])
+
+
+def test_scenes_in_which_the_distance_cull_once_changed_a_pixel(po, meshes, em_scene):
+    """CPU build of the pixel code, default walk: every plane equals the reference's again."""
+    n = 0
+    for name, cam, light, tfs, (w, h) in cull_finding_scenes(po):
+        got = em_scene.render(cam, light, tfs, w, h, screen_cull=True)
+        assert_planes(got, po.render_frame(meshes, tfs, cam, light, w, h), name)
+        n += 1
+    assert n == 3
+
+
+@pytest.mark.gpu
+def test_gpu_scenes_in_which_the_distance_cull_once_changed_a_pixel(capi, gctx, po, meshes):
+    """Through the C ABI with the self-check on: no disagreement of any kind, planes equal to the reference's."""
+    for name, cam, light, tfs, (w, h) in cull_finding_scenes(po):
+        got = gpu_checked(capi, gctx, cam, light, tfs, w, h)
+        assert_planes(got, po.render_frame(meshes, tfs, cam, light, w, h), name)
+        assert_clean(got["counters"], name, min_checks=w * h)
