@@ -1053,7 +1053,11 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
             memcpy(c.root_min, inst[i].root_min, 12); memcpy(c.root_max, inst[i].root_max, 12);
             c.box = instance_box(instances[i].transform, inst[i].root_min, inst[i].root_max);
         }
-        if (!inst[i].empty) { boxes.push_back(c.box); ids.push_back((uint32_t)i); }
+        if (!inst[i].empty) {
+            boxes.push_back(c.box);
+            if (inst[i].wide) reach_camera(boxes.back(), A.cam_pos);
+            ids.push_back((uint32_t)i);
+        }
     }
     ctx->box_allowance = settled_allowance(ctx->box_allowance, scene_box_allowance(boxes, A.cam_pos));
     widen_boxes(boxes, ctx->box_allowance);

@@ -981,6 +981,19 @@ inline InstanceBox instance_box(const rt_transform& tf, const float* bmin, const
     return b;
 }
 
+// The box of an instance of a mesh with MeshArgs::wide reaches as far as the camera: every camera ray then starts inside it
+// (and inside every box of the hierarchy above it), enters it at a distance of zero or less, and no walk over the hierarchy
+// drops it for lying behind the closest hit so far -- the instance is proposed to every camera ray and gets the reference's
+// own root test.  (Shadow rays are not culled by distance in the first place.)
+inline void reach_camera(InstanceBox& b, const float* cam) {
+    for (int i = 0; i < 3; i++) {
+        if (!std::isfinite(cam[i])) continue;
+        const float pad = 1e-3f * (1.0f + fabsf(cam[i]));
+        if (cam[i] - pad < b.lo[i]) b.lo[i] = cam[i] - pad;
+        if (cam[i] + pad > b.hi[i]) b.hi[i] = cam[i] + pad;
+    }
+}
+
 // What the padding above leaves out: the exact test in an instance's own space works on the ray's origin moved into that
 // space, whose rounding error goes with the magnitudes involved -- the instance's position, but also the origin itself: the
 // camera, or, for a shadow ray, a surface point anywhere in the scene.  With an entry placed at 1e30 (the reference accepts any

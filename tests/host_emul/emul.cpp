@@ -346,7 +346,11 @@ int emul_render_instanced(void* sp, const rt_camera* cam, const rt_light* light,
         if (s->loose && !E.pk.loose_tris.empty()) { M.root_ref = M.ref_root = E.pk.loose_root; M.tris = E.pk.loose_tris.data(); }
         set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u; M.wide = E.pk.wide ? 1u : 0u;
         fill_placement(tfs[i], A, M);
-        if (!M.empty) { boxes.push_back(instance_box(tfs[i], M.root_min, M.root_max)); ids.push_back((uint32_t)i); }
+        if (!M.empty) {
+            boxes.push_back(instance_box(tfs[i], M.root_min, M.root_max));
+            if (M.wide) reach_camera(boxes.back(), A.cam_pos);
+            ids.push_back((uint32_t)i);
+        }
     }
     s->box_allowance = settled_allowance(s->box_allowance, scene_box_allowance(boxes, A.cam_pos));
     widen_boxes(boxes, s->box_allowance);
