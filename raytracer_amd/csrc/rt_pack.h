@@ -5,7 +5,6 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -490,7 +489,7 @@ private:
         }
         if (items.size() < 8 || out_.pairs.size() + items.size() >= (size_t)kLeafBit) return;
         leaves_.swap(items);
-        items_per_leaf_ = loose_leaf_tris();
+        items_per_leaf_ = kLooseLeafTris;
         // no deeper than the mesh's other trees, if a balanced tree fits below that: the traversal stack of every kernel,
         // the exact ones included, is sized by the deepest tree of the scene
         int balanced = 1;
@@ -518,11 +517,6 @@ private:
         out_.loose_pairs = (uint32_t)loose.size();
         out_.loose_depth = deepest;
         if (deepest > out_.depth) out_.depth = deepest;
-    }
-    static size_t loose_leaf_tris() {
-        const char* e = getenv("RT_LOOSE_LEAF_TRIS");                      // experiments only
-        const long v = e ? atol(e) : 0;
-        return v >= 1 && v <= 16 ? (size_t)v : kLooseLeafTris;
     }
 
     // ---- flat meshes: where a ray can start its walk ------------------------------------------------
