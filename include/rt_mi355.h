@@ -197,7 +197,7 @@ int rt_render_frames(rt_ctx* ctx, const rt_camera* camera, const rt_light* light
  * forbid hipMalloc in the steady state).  It has no counterpart in the reference.  Same arguments, same launch, same bytes
  * as rt_render_frames with the exact build of the kernels, but the call reaches no allocator: the per-frame constants that
  * rt_render_frames stages in a device buffer of the context go through a file-scope device array of the library
- * (RT_MAX_BATCH records, 31 616 bytes, held by every GPU the library runs on until the process ends; its address on the
+ * (RT_MAX_BATCH records of the per-frame constants, 42 880 bytes, held by every GPU the library runs on until the process ends; its address on the
  * context's GPU is looked up by rt_ctx_create).  Conditions: n_frames <= RT_MAX_BATCH (more: RT_ERR_CAPACITY); the mesh
  * list must not have changed since the last rendering call of this context -- that call put the combined node array on the
  * device; and option "fast" must be off (the entry point promises rt_render_frames' exact bytes) -- otherwise
