@@ -77,6 +77,7 @@ def lib():
         L.emul_regroup_routes_agree.argtypes = [vp, i32, vp, i32]
         L.emul_work_plane.argtypes = [vp, vp]
         L.emul_work_plane.restype = None
+        L.emul_mesh_wide.argtypes = [vp, i32]
         L.emul_set_loose.argtypes = [vp, i32]
         L.emul_set_loose.restype = None
         L.emul_set_vis_shrink.argtypes = [vp, i32]
@@ -210,6 +211,12 @@ class Scene:
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_inst": inst, "hit_tri": tri, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(),
                 "tlas_pairs": pairs.value, "tlas_depth": depth.value}
+
+    def wide(self, mesh: int) -> bool:
+        """Whether the packer marked the mesh as holding a wide triangle (walked without the distance cull)."""
+        r = lib().emul_mesh_wide(self.h, int(mesh))
+        assert r >= 0
+        return bool(r)
 
     def set_loose(self, on: bool):
         """Rays enter every mesh through its tree of single triangles (what the kernels' fast build walks); not bit-exact."""

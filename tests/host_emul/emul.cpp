@@ -141,6 +141,12 @@ int emul_mesh_add(void* sp, const rt_triangle* tris, int32_t n_tris, const rt_fl
     return RT_OK;
 }
 
+// 1 if the packer found a triangle with |e1| |e2| >= kWideTriangle (the mesh is then walked without the distance cull), else 0.
+int emul_mesh_wide(void* sp, int mesh) {
+    EmulScene* s = (EmulScene*)sp;
+    if (mesh < 0 || mesh >= (int)s->meshes.size()) return -1;
+    return s->meshes[(size_t)mesh].pk.wide ? 1 : 0;
+}
 int emul_mesh_info(void* sp, int mesh, int32_t* n_pairs, int32_t* depth, uint32_t* root_ref) {
     EmulScene* s = (EmulScene*)sp;
     if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;

@@ -380,6 +380,23 @@ def cull_finding_scenes(po):
         yield f"scene {r['scene']} of seed {r['seed']}", cam, light, tfs, tuple(r["size"])
 
 
+def test_which_meshes_are_walked_without_the_distance_cull(po, meshes, em_scene):
+    """The drone (rotor discs of 2.8 x 2.8) and the ground (quads of 2 x 2) hold wide triangles, the treasure (|e1||e2| up to 0.12)
+    does not; the same drone at a tenth of its size does not either, and a NaN vertex counts as wide."""
+    assert [em_scene.wide(i) for i in range(3)] == [True, False, True]
+    s = emul.Scene(regroup=True)
+    small = meshes[0].tris.copy()
+    small[:, :9] *= np.float32(0.1)
+    t, n = po.build_bvh(small)
+    assert s.add(t, n, meshes[0].rgba) == 0
+    broken = meshes[1].tris.copy()
+    broken[7, 4] = np.float32("nan")
+    t, n = po.build_bvh(broken)
+    assert s.add(t, n, meshes[1].rgba) == 0
+    assert [s.wide(0), s.wide(1)] == [False, True]
+    s.close()
+
+
 def test_scenes_in_which_the_distance_cull_once_changed_a_pixel(po, meshes, em_scene):
     """CPU build of the pixel code, default walk: every plane equals the reference's again."""
     n = 0
