@@ -1,5 +1,5 @@
 #!/bin/bash
-# Measurement pass of round 3 in one GPU call: smoke, the bench as the driver runs it and with its defaults, the rocprofv3
+# The measurement pass in one GPU call: smoke, the bench as the driver runs it and with its defaults, the rocprofv3
 # kernel trace of the same command, the counter passes over the bench's own launches, the bench through RCCL with one rank.
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
