@@ -155,7 +155,7 @@ int rt_mesh_count(const rt_ctx* ctx);
  * plane at less than about 2e-4 rad, where ray.c:42-67 can put a hit percents in front of the surface; the reference keeps
  * such a hit.  Meshes that hold a triangle with |e1| |e2| >= 0.25 -- large enough for ray.c:50's cut-off to admit such rays
  * over a noticeable area -- are walked without that skip (found and checked with RT_FLAG_VERIFY_SKIPS: 3 rays in 3.6e10
- * before, none in 116e9 checked decisions since).  RT_FLAG_REFERENCE_ORDER is the walk that skips nothing for any mesh. */
+ * before, none in 348e9 checked decisions since).  RT_FLAG_REFERENCE_ORDER is the walk that skips nothing for any mesh. */
 #define RT_FLAG_REFERENCE_ORDER 0x2u /* traverse every box the reference would, in its order, no distance culling */
 /* Self-check of everything the kernels skip by geometry.  The frame is rendered as without the flag (one lane per ray), but
  * wherever a shortcut is taken the kernel ALSO does what the reference would have done and counts the cases in which that
