@@ -676,3 +676,43 @@ def test_tree_over_the_triangles_themselves_reaches_the_same_surfaces(po, meshes
         seen_exact |= set(np.unique(a["hit_id"]).tolist())
         seen_loose |= set(np.unique(b["hit_id"]).tolist())
     assert len(seen_exact) > 300 and len(seen_exact ^ seen_loose) <= 2
+
+
+def test_flat_soups_of_overlapping_random_triangles_through_the_grid(po):
+    """Flat meshes that are not sheets: random triangles of one plane lying on top of each other, needles and specks among
+    them, so that a cell of the grid is covered by many leaves and its triangle masks decide what is tested (Packer::tri_mask;
+    needles are outside its argument and must always be kept).  Default walk, the walk with tiles skipped by rectangles and
+    the self-checking walk against the oracle, steep and grazing views."""
+    rng = np.random.default_rng(23)
+    tex = checker()
+    for trial in range(10):
+        axis = trial % 3
+        n = int(rng.choice([40, 200, 600]))
+        soup = (rng.normal(size=(n, 24)) * float(rng.choice([0.3, 1.0, 3.0]))).astype(np.float32)
+        thin = rng.uniform(size=n) < 0.15                                   # needles: the third vertex almost on the first edge
+        soup[thin, 6:9] = soup[thin, 0:3] + (soup[thin, 3:6] - soup[thin, 0:3]) * np.float32(0.7) + rng.normal(size=(int(thin.sum()), 3)).astype(np.float32) * np.float32(1e-5)
+        speck = rng.uniform(size=n) < 0.1
+        soup[speck, 3:9] = np.tile(soup[speck, 0:3], 2) + rng.normal(size=(int(speck.sum()), 6)).astype(np.float32) * np.float32(1e-3)
+        soup[:, [axis, 3 + axis, 6 + axis]] = np.float32(rng.normal() * 0.3)
+        t, nodes = po.build_bvh(soup)
+        mesh = po.HostMesh(t, nodes, tex)
+        tfs = [po.Transform(po.vec3(*rng.normal(size=3) * 0.3), po.vec3(*rng.uniform(-1, 1, size=3)))]
+        eye = rng.normal(size=3) * 3.0
+        if trial % 2:
+            eye[axis] *= 0.02                                                # grazing
+        cam = po.Camera(po.vec3(*eye), po.vec3(*rng.normal(size=3) * 0.3), po.vec3(0, 1, 0), float(rng.choice([25.0, 70.0])))
+        ld = rng.normal(size=3); ld /= np.linalg.norm(ld)
+        light = po.Light(po.vec3(*np.array(ld, np.float32)), po.vec3(1.2, 1.1, 1.0))
+        w, h = 160, 90
+        want = po.render_frame([mesh], tfs, cam, light, w, h)
+        s = emul.Scene(regroup=True)
+        assert s.add(mesh.tris, mesh.nodes, mesh.rgba) == 0, s.error()
+        for mode in ({"full": False}, {"screen_cull": True}, {"verify": True}):
+            got = s.render(cam, light, tfs, w, h, **mode)
+            for k, ref in (("hit_id", want.hit_id), ("shadow", want.shadow), ("rgb", want.rgb)):
+                assert np.array_equal(got[k], ref), f"trial {trial} axis {axis} n {n} {mode}: {k}"
+            assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t)), (trial, mode)
+            if mode.get("verify"):
+                c = got["counters"]
+                assert c["entry_disagreements"] == 0 and c["cull_disagreements"] == 0 and c["vis_disagreements"] == 0, (trial, c)
+        s.close()
