@@ -362,7 +362,8 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * whatever this option says; rt_render_frame_sampled always does), "instanced_wave" (rt_render_frame_instanced: 0, default = one lane per pixel walks
  * hierarchy, instance and triangles as nested loops; 1..8 = every lane is a state machine and the wave executes the step most of
  * its lanes wait for, lanes taking new pixels from a strip of that many tiles -- more lanes busy per instruction, more
- * instructions: measured slower, kept for comparison).
+ * instructions: measured slower, kept for comparison; it culls by distance inside every instance, so a list that places a mesh
+ * with a triangle of |e1| |e2| >= 0.25, which is walked without that cull, is rendered by the default kernel all the same).
  * Every setting except "fast" produces the same image.  Read-only: "n_variants", "default_variant".
  * Unknown names give RT_ERR_INVALID. */
 int rt_set_option(rt_ctx* ctx, const char* name, int value);

@@ -1039,6 +1039,7 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
         memcpy(ctx->inst_cache_cam, A.cam_pos, 12); memcpy(ctx->inst_cache_light, A.light_dir, 12);
     }
     ctx->inst_cache.resize((size_t)n_instances);
+    bool any_wide = false;
     for (int32_t i = 0; i < n_instances; i++) {
         inst[i] = ctx->meshes[(size_t)instances[i].mesh].proto;
         if (runs_fast(ctx, flags)) enter_loose_tree(ctx->meshes[(size_t)instances[i].mesh], inst[i]);
@@ -1055,7 +1056,7 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
         }
         if (!inst[i].empty) {
             boxes.push_back(c.box);
-            if (inst[i].wide) reach_camera(boxes.back(), A.cam_pos);
+            if (inst[i].wide) { reach_camera(boxes.back(), A.cam_pos); any_wide = true; }
             ids.push_back((uint32_t)i);
         }
     }
@@ -1084,8 +1085,11 @@ int rt_render_frame_instanced(rt_ctx* ctx, const rt_camera* camera, const rt_lig
         ctx->counters_pending = true;
     }
     if (ctx->timing) RT_HIP(ctx, hipEventRecord(ctx->ev_begin, s));
-    hipError_t le = runs_fast(ctx, flags) ? rt_fast_launch_instanced(&A, &I, &S, &O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, ctx->instanced_wave, s)
-                                          : launch_instanced(A, I, S, O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, ctx->instanced_wave, s);
+    // The per-wavefront scheduler culls by distance inside every instance; a list that places a mesh which must be walked without
+    // that cull (MeshArgs::wide) is rendered by the default kernel whatever the option says.
+    const int wave_tiles = any_wide ? 0 : ctx->instanced_wave;
+    hipError_t le = runs_fast(ctx, flags) ? rt_fast_launch_instanced(&A, &I, &S, &O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, wave_tiles, s)
+                                          : launch_instanced(A, I, S, O, (int32_t*)d_hit_tri, T.depth + 2, ctx->cfg.block, wave_tiles, s);
     if (le != hipSuccess) return hip_fail(ctx, le, "kernel launch");
     if (ctx->timing) { RT_HIP(ctx, hipEventRecord(ctx->ev_end, s)); ctx->ev_pending = true; }
     RT_HIP(ctx, hipEventRecord(ctx->inst_done[slot], s));

@@ -91,7 +91,7 @@ __device__ __forceinline__ void start_pixel(WaveLane<BLOCK>& L, const FrameArgs&
 }
 
 // One box pair: both children's slab tests, nearer child first, the farther one parked (trace_mesh's inner step).
-// (This form keeps the distance cull inside every instance, MeshArgs::wide or not: it is the comparison variant, not the default.)
+// (This form keeps the distance cull inside every instance; the host does not launch it for a list that places a MeshArgs::wide mesh.)
 template <int BLOCK>
 __device__ __forceinline__ void step_box(WaveLane<BLOCK>& L) {
     const PairNode N = L.base[L.ref];

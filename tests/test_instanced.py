@@ -486,6 +486,10 @@ def test_gpu_wave_scheduled_kernel_equals_reference_loop(gscene, po, meshes, til
             ids, tfs = grid_scene(po, n_side, seed=n_side)
             fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), *size)
             check(gpu_render(gscene, po, ids, tfs, *size), fr, inst, tri)
+            # the treasures alone: drone and ground hold large triangles, and a list that places one of them goes to the
+            # default kernel whatever the option says -- without them the scheduler itself renders
+            fr, inst, tri = oracle_planes(po, meshes, ids[2:], tfs[2:], po.default_camera(), po.default_light(), *size)
+            check(gpu_render(gscene, po, ids[2:], tfs[2:], *size), fr, inst, tri)
         t = po.animation_transforms(7)
         ids, tfs = [1, 0, 1, 2, 1], [t[1], t[0], t[1], t[2], t[1]]                    # the treasure three times in one place
         fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), 200, 120)
