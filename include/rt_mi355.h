@@ -174,6 +174,9 @@ int rt_mesh_count(const rt_ctx* ctx);
  *   d_hit_id  width*height int32: (mesh_id<<24)|triangle index, -1 = miss   -- optional (NULL)
  *   d_hit_t   width*height float: closest_t, 1e30f = miss                    -- optional
  *   d_shadow  width*height uint8: 1 blocked, 0 lit, 255 = no primary hit     -- optional
+ * A call that takes no d_shadow and counts nothing (so also rt_render_frames, rt_render_frame_sampled and the instanced frame
+ * without that plane) sends no shadow ray from a surface whose own term max(0.2, n.L) is 0.2 already: scene.c:143-144 then
+ * gives diffuse = 0.2 blocked or not, and every byte of the other planes is the same.
  * The launch is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the context's
  * own stream).  Inputs are consumed before the call returns. */
 int rt_render_frame(rt_ctx* ctx, const rt_camera* camera, const rt_light* light,

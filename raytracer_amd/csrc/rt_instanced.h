@@ -15,7 +15,7 @@ namespace rt {
 
 struct InstancedOut {
     uint8_t r, g, b;
-    uint8_t shadow;      // 1 blocked, 0 lit, 255 no primary hit
+    uint8_t shadow;      // 1 blocked, 0 lit, 255 no primary hit (2: no shadow ray sent, colour_only)
     int32_t inst;        // winning instance or -1
     int32_t tri;         // its triangle or -1
     float hit_t;
@@ -80,7 +80,7 @@ RT_HD void take_walk_fields(const MeshArgs& M, MeshArgs& W) {
 
 template <bool COUNT, class Stack, class TStack, class Nodes, class Party>
 RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs& I, const Nodes& nodes, const Party& party, int px, int py,
-                                         Stack& stack, TStack& tstack, Work& work) {
+                                         Stack& stack, TStack& tstack, Work& work, const bool colour_only = false) {
     InstancedOut out;
     // ---- camera ray (camera.c:12-30) ----
     const float fx = ((float)px + 0.5f) / (float)A.width;
@@ -168,8 +168,12 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
     const F3 so = add(add(wo, scale(wd, closest)), scale(n, 0.001f));
     const F3 L = f3(A.light_dir);
     bool dark = false;
-    walk.begin(I, so, recip(L), tstack);
-    while (!dark) {
+    // a caller that stores nothing but the colour: where max(0.2, n.L) is 0.2 already, scene.c:143-144 gives 0.2 blocked or not,
+    // and the shadow ray is not sent (shade_pixel does the same)
+    const float facing = dot(n, L);
+    const bool unsent = colour_only && !COUNT && !Party::kVerify && !(facing > 0.2f);
+    if (!unsent) walk.begin(I, so, recip(L), tstack);
+    while (!dark && !unsent) {
         MeshArgs W;
         F3 lo = so, sd = L, sinv = L;
         const int i = walk.next(I, tstack, []() { return 3.0e38f; }, [&](uint32_t k) {
@@ -199,12 +203,12 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
         if (ref_dark != dark) work.bad_inst++;
     }
     float diffuse = 0.2f;
-    if (!dark) diffuse = fmaxf(diffuse, dot(n, L));
+    if (!dark) diffuse = fmaxf(diffuse, facing);
     color = scale(mul(color, f3(A.light_color)), diffuse);
     out.r = colour_byte(color.x);
     out.g = colour_byte(color.y);
     out.b = colour_byte(color.z);
-    out.shadow = dark ? 1 : 0;
+    out.shadow = dark ? 1 : (unsent ? 2 : 0);
     out.dark = dark ? 1 : 0;
     return out;
 }

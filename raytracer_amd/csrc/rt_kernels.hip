@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const 
     if (active) {
         PixelOut r;
         if (VERIFY) r = shade_pixel<COUNT, FULL, false>(A, nodes, SoloVerify(), px, py, stack, work);
-        else r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work);
+        else r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work, O.shadow == nullptr);
         store_pixel(O, A.width, px, py, r);
         tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
     }
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(BLOCK, VERIFY ? 1 : 5) render_instanced(const 
     if (px < A.width && py < A.height) {
         InstancedOut r;
         if (VERIFY) r = shade_instanced_pixel<COUNT>(A, I, nodes, SoloVerify(), px, py, stack, tstack, work);
-        else r = shade_instanced_pixel<COUNT>(A, I, nodes, Solo(), px, py, stack, tstack, work);
+        else r = shade_instanced_pixel<COUNT>(A, I, nodes, Solo(), px, py, stack, tstack, work, O.shadow == nullptr);
         const size_t p = (size_t)py * (size_t)A.width + (size_t)px;
         uint8_t* rgb = O.rgb + p * 3;
         rgb[0] = r.r; rgb[1] = r.g; rgb[2] = r.b;
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) render_lean(const FrameArgs A, co
     const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
     if (px < A.width && py < A.height) {
         Work work; work.slabs = 0; work.tris = 0;
-        const PixelOut r = shade_pixel<false, false, false>(A, nodes, SoloT<LB>(), px, py, stack, work);
+        const PixelOut r = shade_pixel<false, false, false>(A, nodes, SoloT<LB>(), px, py, stack, work, O.shadow == nullptr);
         store_pixel(O, A.width, px, py, r);
     }
     if (O.tile_clock && (threadIdx.x & 63) == 0 && tile < tiles_x * ((A.height + 7) >> 3)) {
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(BLOCK, DEPTH <= 16 ? kBatchWaves : 5) render_b
     const int px = col * 8 + (lane & 7), py = row * 8 + (lane >> 3);
     if (px < A.width && py < A.height) {
         Work work; work.slabs = 0; work.tris = 0;
-        const PixelOut r = shade_pixel<false, false, false>(A, nodes, SoloT<LB>(), px, py, stack, work);
+        const PixelOut r = shade_pixel<false, false, false>(A, nodes, SoloT<LB>(), px, py, stack, work, true);
         uint8_t* rgb = rgb_base + (size_t)f * frame_stride + ((size_t)py * (size_t)A.width + (size_t)px) * 3;
         rgb[0] = r.r; rgb[1] = r.g; rgb[2] = r.b;
     }
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(BLOCK) render_tiles(const FrameArgs A, const S
             party.area = &lds_stack[threadIdx.x & ~7u];
             LdsStack<BLOCK> unused_stack; unused_stack.init(nullptr);
             Work work; work.slabs = 0; work.tris = 0;
-            const PixelOut r = shade_pixel<false, false, false>(A, nodes, party, px, py, unused_stack, work);
+            const PixelOut r = shade_pixel<false, false, false>(A, nodes, party, px, py, unused_stack, work, O.shadow == nullptr);
             if ((lane & 7) == 0) store_pixel(O, A.width, px, py, r);
         }
     } else {
@@ -833,7 +833,7 @@ __global__ void __launch_bounds__(BLOCK) render_tiles(const FrameArgs A, const S
             LdsStack<BLOCK> stack;
             stack.init(&lds_stack[threadIdx.x]);
             Work work; work.slabs = 0; work.tris = 0;
-            const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work);
+            const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work, O.shadow == nullptr);
             store_pixel(O, A.width, px, py, r);
             tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
         }
@@ -941,7 +941,7 @@ __global__ void __launch_bounds__(kPass2Block) render_pass2(const FrameArgs A, c
             const uint32_t id = items[at];
             const int py = (int)(id / (uint32_t)A.width), px = (int)(id - (uint32_t)py * (uint32_t)A.width);
             Work work; work.slabs = 0; work.tris = 0;
-            const PixelOut r = shade_pixel<false, false, false>(A, nodes, party, px, py, unused_stack, work);
+            const PixelOut r = shade_pixel<false, false, false>(A, nodes, party, px, py, unused_stack, work, O.shadow == nullptr);
             if ((lane & 7) == 0) store_pixel(O, A.width, px, py, r);
         }
     }
@@ -999,7 +999,7 @@ __global__ void __launch_bounds__(kResidentBlock) render_resident(const FrameArg
         const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
         if (px < A.width && py < A.height) {
             Work work; work.slabs = 0; work.tris = 0;
-            const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work);
+            const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work, O.shadow == nullptr);
             store_pixel(O, A.width, px, py, r);
             if (COUNT) { tot.pixels += 1; tot.hits += r.hit; tot.darks += r.dark; tot.slabs += work.slabs; tot.tris += work.tris; }
         }

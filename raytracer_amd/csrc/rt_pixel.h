@@ -537,7 +537,7 @@ struct SoloBudget {
 
 struct PixelOut {
     uint8_t r, g, b;
-    uint8_t shadow;      // 1 blocked, 0 lit, 255 no primary hit
+    uint8_t shadow;      // 1 blocked, 0 lit, 255 no primary hit (2: no shadow ray sent, colour_only)
     int32_t hit_id;      // (mesh<<24)|tri or -1
     float hit_t;
     uint32_t hit;        // 0/1
@@ -550,8 +550,12 @@ RT_HD int frame_row(const FrameArgs& A, int py) { return ((py >> 3) * A.strip_st
 
 // DEFER=true gives up as soon as the party reports that its budget is exhausted and returns with
 // `deferred` set; nothing of such a pixel is stored.
+// colour_only is for callers that store nothing but the colour (no shadow plane, no counters): where the surface's own term
+// max(0.2, n.L) is 0.2 already (it faces away from the light, or nearly), scene.c:143-144 gives diffuse = 0.2 blocked or not,
+// and the shadow ray is not sent (`shadow` reads 2, `dark` 0).  Counting, reference-order and self-checking runs send every ray.
 template <bool COUNT, bool FULL, bool DEFER, class Stack, class Nodes, class Party>
-RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& party, int px, int py, Stack& stack, Work& work) {
+RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& party, int px, int py, Stack& stack, Work& work,
+                           const bool colour_only = false) {
     PixelOut out;
     out.deferred = 0;
     // ---- camera ray (camera.c:12-30; basis and tan() hoisted to the host) ----
@@ -617,7 +621,11 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     const F3 p = add(wo, scale(wd, closest));
     const F3 so = add(p, scale(n, 0.001f));
     bool dark = false;
-    for (int m = 0; m < A.n_mesh && !dark; m++) {
+    const F3 L = f3(A.light_dir);
+    const float facing = dot(n, L);
+    const bool unsent = colour_only && !COUNT && !FULL && !Party::kVerify && !(facing > 0.2f);   // a NaN compares false: fmaxf(0.2f, NaN) is 0.2f as well
+    const int n_shadow = unsent ? 0 : A.n_mesh;
+    for (int m = 0; m < n_shadow && !dark; m++) {
         const MeshArgs& S = A.mesh[m];
         // outside A.vis_shadow[m] no surface point seen in this tile can send its shadow ray through the mesh's root box
         if (!COUNT && !FULL && (tile_x < A.vis_shadow[m][0] || tile_x >= A.vis_shadow[m][2] || tile_y < A.vis_shadow[m][1] || tile_y >= A.vis_shadow[m][3])) {
@@ -634,13 +642,12 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
         if (DEFER && party.exhausted()) { out.deferred = 1; return out; }
     }
     float diffuse = 0.2f;                                              // scene.c:115
-    const F3 L = f3(A.light_dir);
-    if (!dark) diffuse = fmaxf(diffuse, dot(n, L));                    // scene.c:143-144
+    if (!dark) diffuse = fmaxf(diffuse, facing);                       // scene.c:143-144
     color = scale(mul(color, f3(A.light_color)), diffuse);             // scene.c:148-149
     out.r = colour_byte(color.x);                // scene.c:152-154 (truncation)
     out.g = colour_byte(color.y);
     out.b = colour_byte(color.z);
-    out.shadow = dark ? 1 : 0;
+    out.shadow = dark ? 1 : (unsent ? 2 : 0);
     out.dark = dark ? 1 : 0;
     return out;
 }

@@ -105,13 +105,17 @@ RT_HD F3 sample_value(const FrameArgs& A, const SampleArgs& X, const Nodes& node
         F3 color = f3(0.0f, 0.0f, 0.0f);
         for (int l = 0; l < X.n_lights; l++) {
             bool dark = false;
-            for (int m = 0; m < A.n_mesh && !dark; m++) {
+            // Only the colour leaves a sampled frame (and, when counting, the number of blocked rays): where max(0.2, n.L) is 0.2
+            // already, scene.c:143-144 gives 0.2 blocked or not, and the shadow ray towards this light is not sent.
+            const float facing = dot(n, f3(X.light_dir[l]));
+            const int n_shadow = (!COUNT && !Party::kVerify && !(facing > 0.2f)) ? 0 : A.n_mesh;
+            for (int m = 0; m < n_shadow && !dark; m++) {
                 const MeshArgs& S = A.mesh[m];
                 const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);
                 dark = party.template any<COUNT, false>(S, nodes, lo, f3(X.lit_d[m][l]), f3(X.lit_inv[m][l]), stack, work);
             }
             float diffuse = 0.2f;
-            if (!dark) diffuse = fmaxf(diffuse, dot(n, f3(X.light_dir[l])));
+            if (!dark) diffuse = fmaxf(diffuse, facing);
             else out.darks++;
             const F3 term = scale(mul(tex, f3(X.light_color[l])), diffuse);
             color = l == 0 ? term : add(color, term);

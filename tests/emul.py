@@ -165,7 +165,7 @@ class Scene:
         assert lib().emul_mesh_prios(self.h, mesh, out.ctypes.data) == 0
         return out
 
-    def render(self, cam, light, tfs, w, h, full=False, per_pixel=False, screen_cull=False, verify=False):
+    def render(self, cam, light, tfs, w, h, full=False, per_pixel=False, screen_cull=False, verify=False, colour_only=False):
         arr = (Transform * max(len(tfs), 1))(*[conv(t, Transform) for t in tfs])
         rgb = np.zeros((h, w, 3), np.uint8)
         hid = np.zeros((h, w), np.int32)
@@ -176,7 +176,7 @@ class Scene:
         pt = np.zeros((h, w), np.uint32) if per_pixel else None
         cam2, light2 = conv(cam, Camera), conv(light, Light)
         st = lib().emul_render(self.h, C.byref(cam2), C.byref(light2), arr, len(tfs), w, h, rgb.ctypes.data,
-                               hid.ctypes.data, ht.ctypes.data, sh.ctypes.data, C.byref(cnt), 3 if verify else (2 if screen_cull else (1 if full else 0)),
+                               hid.ctypes.data, ht.ctypes.data, sh.ctypes.data, C.byref(cnt), 4 if colour_only else (3 if verify else (2 if screen_cull else (1 if full else 0))),
                                ps.ctypes.data if per_pixel else None, pt.ctypes.data if per_pixel else None)
         assert st == 0, self.error()
         return {"rgb": rgb, "hit_id": hid, "hit_t": ht, "shadow": sh, "counters": cnt.as_dict(), "px_slabs": ps,

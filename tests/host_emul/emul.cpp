@@ -241,10 +241,11 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
             Work w;
             // full: 1 = reference visiting order; 0 = nearer child first with distance culling; 2 = the same without work
             // counts, as the kernels run it: meshes are skipped for tiles outside their screen rectangle; 3 = as 2 with the
-            // self-checking party (RT_FLAG_VERIFY_SKIPS)
+            // self-checking party (RT_FLAG_VERIFY_SKIPS); 4 = as 2 for a caller that stores the colour only (rt_render_frames' kernel)
             PixelOut r = full == 1 ? shade_pixel<true, true, false>(A, nodes, Solo(), x, y, st, w)
                        : full == 2 ? shade_pixel<false, false, false>(A, nodes, Solo(), x, y, st, w)
                        : full == 3 ? shade_pixel<false, false, false>(A, nodes, SoloVerify(), x, y, st, w)
+                       : full == 4 ? shade_pixel<false, false, false>(A, nodes, Solo(), x, y, st, w, true)
                                    : shade_pixel<true, false, false>(A, nodes, Solo(), x, y, st, w);
             row.add(w);
             const size_t p = (size_t)y * width + x;

@@ -430,6 +430,9 @@ def test_degenerate_cameras_lights_and_placements_on_the_gpu(capi, po, meshes):
                 rgb, hid, ht, sh = c.render_host(ccam, light, ctf, w, h)
                 assert np.array_equal(hid, want.hit_id) and np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32)), f"{name}: variant {variant}"
                 assert np.array_equal(sh, want.shadow) and np.array_equal(rgb, want.rgb), f"{name}: variant {variant}"
+                # without the planes a call sends no shadow ray where it cannot change the colour: same bytes
+                rgb_only, _, _, _ = c.render_host(ccam, light, ctf, w, h, debug=False)
+                assert np.array_equal(rgb_only, want.rgb), f"{name}: variant {variant}, colour only"
             c.set_option("variant", c.get_option("default_variant"))
             out = torch.zeros((2, h, w, 3), dtype=torch.uint8, device="cuda:0")
             smp = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")

@@ -146,6 +146,20 @@ def test_all_kernel_variants_agree(capi, ctx, po, golden_frames):
         ctx.set_option("block", 64)
 
 
+def test_frames_without_planes_carry_the_same_colours(capi, ctx, po, golden_frames):
+    """rt_render_frame_host without the hit and shadow planes: no shadow ray is sent where it cannot change the colour
+    (max(0.2, n.L) is 0.2 already, scene.c:143-144); the colours are the golden frames' in every kernel variant."""
+    cam, light = cam_light(capi, po)
+    try:
+        for variant in range(ctx.get_option("n_variants")):
+            ctx.set_option("variant", variant)
+            for frame in (0, 45, 95):
+                rgb, _, _, _ = ctx.render_host(cam, light, to_capi_tfs(capi, po.animation_transforms(frame)), 240, 135, debug=False)
+                assert np.array_equal(rgb, golden_frames[f"f{frame}_rgb"]), f"variant {variant}, frame {frame}"
+    finally:
+        ctx.set_option("variant", ctx.get_option("default_variant"))
+
+
 @pytest.mark.parametrize("block", [64, 256])
 def test_batched_frames_equal_single_frames(capi, ctx, po, golden_hashes, block):
     """rt_render_frames: every frame of a batch carries the bytes the single-frame entry point produces."""

@@ -609,6 +609,41 @@ def test_degenerate_cameras_lights_and_placements_give_the_reference_bytes(po, e
     assert n >= 20
 
 
+def test_shadow_rays_that_cannot_change_the_colour_are_left_out_without_changing_it(po, meshes, em_default):
+    """A caller that stores the colour only (rt_render_frames, calls without a shadow plane): where max(0.2, n.L) is 0.2
+    already, scene.c:143-144 gives diffuse 0.2 blocked or not, and the pixel code sends no shadow ray.  The colours stay the
+    oracle's byte for byte -- golden frames, random placements and lights (negative and above-one colours), the degenerate
+    views (NaN lights and normals among them) -- and rays are in fact left out where surfaces face away from the light."""
+    import adversarial
+    unsent = 0
+    for frame in (0, 45, 95):
+        tfs = po.animation_transforms(frame)
+        want = po.render_frame(meshes, tfs, po.default_camera(), po.default_light(), 240, 135)
+        got = em_default.render(po.default_camera(), po.default_light(), tfs, 240, 135, colour_only=True)
+        assert np.array_equal(got["rgb"], want.rgb) and np.array_equal(got["hit_id"], want.hit_id)
+        assert np.array_equal(bits(got["hit_t"]), bits(want.hit_t))
+        sent = got["shadow"] != 2
+        assert np.array_equal(got["shadow"][sent], want.shadow[sent])            # the rays that were sent end as the oracle's
+        assert ((got["hit_id"] >> 24)[~sent] != 2).all()                         # the ground faces the light: all of its rays go out
+        unsent += int((~sent).sum())
+    assert unsent > 500
+    rng = np.random.default_rng(17)
+    for _ in range(8):
+        tfs = [po.Transform(po.vec3(*rng.uniform(-1.5, 1.5, 3)), po.vec3(*rng.uniform(-3.2, 3.2, 3))) for _ in range(2)]
+        tfs.append(po.Transform(po.vec3(0, 0, 0), po.vec3(*rng.uniform(-0.05, 0.05, 3))))
+        eye = rng.uniform(-4, 4, 3)
+        eye[1] = abs(eye[1]) + 1.0
+        cam = po.Camera(po.vec3(*eye), po.vec3(0, 0.3, 0), po.vec3(0, 1, 0), float(rng.uniform(30, 90)))
+        light = po.lib().orc_make_light(po.vec3(*rng.uniform(-1, 1, 3)), po.vec3(*rng.uniform(-0.5, 1.6, 3)))
+        want = po.render_frame(meshes, tfs, cam, light, 96, 54)
+        got = em_default.render(cam, light, tfs, 96, 54, colour_only=True)
+        assert np.array_equal(got["rgb"], want.rgb)
+    for name, tfs, cam, light in adversarial.degenerate_views(po):
+        want = po.render_frame(po.default_meshes(), tfs, cam, light, 96, 54)
+        got = em_default.render(cam, light, tfs, 96, 54, colour_only=True)
+        assert np.array_equal(got["rgb"], want.rgb), name
+
+
 def test_meshes_with_nan_and_infinite_vertices_through_the_host_build_of_the_pixel_code(po):
     """tests/adversarial.py::nonfinite_soups as meshes: packer (both trees) and traversal (both modes) on boxes with NaN and
     infinite bounds against the oracle's reference loop, every plane."""

@@ -475,6 +475,28 @@ def test_gpu_successive_calls_with_partly_changed_lists(gscene, po, meshes):
 
 
 @pytest.mark.gpu
+def test_gpu_frame_without_a_shadow_plane_has_the_same_colours(gscene, po, meshes):
+    """A call that asks for no shadow plane sends no shadow ray where it cannot change the colour (surfaces whose own term
+    max(0.2, n.L) is 0.2 already): colour, instance, triangle and distance planes stay the reference loop's."""
+    import torch
+    from raytracer_amd import capi
+    ids, tfs = grid_scene(po, 6, seed=3)
+    w, h = 321, 187
+    fr, inst, tri = oracle_planes(po, meshes, ids, tfs, po.default_camera(), po.default_light(), w, h)
+    cam = capi.Camera(capi.Vec3(-3, 3, -3), capi.Vec3(0, 0, 0), capi.Vec3(0, 1, 0), 60.0)
+    l = po.default_light()
+    light = capi.Light(capi.Vec3(*l.direction.tup()), capi.Vec3(*l.color.tup()))
+    placed = capi.Context.make_instances(ids, [capi.Transform(capi.Vec3(*t.position.tup()), capi.Vec3(*t.rotation.tup())) for t in tfs])
+    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    hi = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+    ht = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
+    gscene.render_instanced(cam, light, placed, w, h, rgb, hit_instance=hi, hit_tri=ht)
+    gscene.sync()
+    assert np.array_equal(rgb.cpu().numpy(), fr.rgb)
+    assert np.array_equal(hi.cpu().numpy(), inst) and np.array_equal(ht.cpu().numpy()[inst >= 0], tri[inst >= 0])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tiles", [1, 4])
 def test_gpu_wave_scheduled_kernel_equals_reference_loop(gscene, po, meshes, tiles):
     """Option "instanced_wave": the per-wavefront scheduler (every lane a state machine, lanes refilled from a strip of
