@@ -71,6 +71,8 @@ def parse(argv=None):
                    help="frames per launch (and per gather message for N > 1); 0: FRAMES_PER_LAUNCH on one GPU, half of it on several "
                         "(shorter messages: more of the gather travels behind the next launch)")
     p.add_argument("--block", type=int, default=0)
+    p.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                   help="library option for the rendering context (rt_set_option), e.g. batch_chunk=480; may be given several times")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--verbose", action="store_true", help="phase markers on stderr")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -285,6 +287,9 @@ def main():
         ctx = scene.ctx
         if a.block:
             ctx.set_option("block", a.block)
+        for item in a.set:
+            name, _, number = item.partition("=")
+            ctx.set_option(name, int(number))
         NF = demo.N_FRAMES
         # An explicit stream, made torch's current one: the kernels are launched on it, and RCCL orders
         # its gathers after the work already queued on the current stream.
@@ -388,7 +393,11 @@ def main():
         times.append(timed_pass())
     say(f"timed region: {repeats} repetitions, median {sorted(times)[len(times) // 2]:.4f} s")
 
-    rays_rank = sum(info[f]["primary_rays"] + info[f]["shadow_rays"] for f in seq)
+    # Rays of the timed steps.  The kernel stores the colour only, and sends no shadow ray from a surface whose own term
+    # max(0.2, n.L) is 0.2 already (scene.c:143-144 gives 0.2 blocked or not): those rays (counted by the untimed runs above,
+    # which send them) are left out of `value`, which so counts the rays that were traversed.
+    idle_rank = sum(info[f].get("idle_shadow_rays", 0) for f in seq)
+    rays_rank = sum(info[f]["primary_rays"] + info[f]["shadow_rays"] for f in seq) - idle_rank
     if grouped:
         tmax = torch.tensor(times, dtype=torch.float64, device=dev)      # per repetition: the slowest rank
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -463,7 +472,8 @@ def main():
                                    "box_tests_per_launch": int(np.mean([sum(own[f]["slab_tests"] for f in batches[i]) for i in full])),
                                    "triangle_tests_per_launch": int(np.mean([sum(own[f]["tri_tests"] for f in batches[i]) for i in full])),
                                    "TFLOP/s": round(float(np.mean(own_flops)) / secs / 1e12, 3),
-                                   "basis": "tests the ordered, distance-culled traversal of the kernel executes"},
+                                   "basis": "tests the ordered, distance-culled traversal of the kernel executes, counted by runs that send every shadow ray: "
+                                            "the tests of the rays the timed kernel leaves out (see rays) are included"},
                 "note": "the scene (150 KB of nodes, 170 KB of triangles) is cache resident: the algorithmic bytes are served by "
                         "L1/L2 (cache_served_GBs), HBM carries the framebuffers and texels only"}
         # the same launches with the fast build of the kernels (context option "fast": fused multiply-adds, approximate
@@ -540,6 +550,13 @@ def main():
             "gather_budget": gather_budget(W, H, a.steps / dt_all, world, grouped and world > 1),
             "frames_per_s": round(a.steps * world / dt_all, 2),
             "rays_per_frame": int(rays_rank / a.steps),
+            "rays": {"per_frame_in_value": int(rays_rank / a.steps),
+                     "per_frame_of_the_reference": int((rays_rank + idle_rank) / a.steps),
+                     "shadow_rays_not_sent_per_frame": int(idle_rank / a.steps),
+                     "value_counting_the_reference_rays": round(rays_all * (1.0 + idle_rank / max(rays_rank, 1)) / dt_all / 1e6, 2),
+                     "note": "rank 0's frames; the reference sends a shadow ray from every hit (scene.c:117-139); the kernel stores the colour only and "
+                             "sends none from a surface whose term max(0.2, n.L) is 0.2 already -- scene.c:143-144 gives diffuse 0.2 blocked "
+                             "or not, the bytes are the reference's -- and `value` does not count those rays"},
             "single_frame_kernel_ms": single_ms,
             "roofline": roof,
             "fast_build": fast,

@@ -92,6 +92,10 @@ typedef struct {
      *                             reference's loop over the whole mesh list (scene.c:72-108, 124-139) */
     uint64_t skip_checks;
     uint64_t vis_disagreements, shadow_vis_disagreements, entry_disagreements, cull_disagreements, instance_disagreements;
+    /* RT_FLAG_COUNT_WORK: how many of shadow_rays start on a surface whose own term max(0.2, n.L) is 0.2 already, so that
+     * scene.c:143-144 gives diffuse = 0.2 whatever they meet.  A counting call sends them like the reference; a call that
+     * stores the colour only does not (see rt_render_frame). */
+    uint64_t idle_shadow_rays;
 } rt_counters;
 
 /* ---- context --------------------------------------------------------------------------- */

@@ -1325,7 +1325,7 @@ int rt_last_counters(rt_ctx* ctx, rt_counters* out) {
     out->primary_rays = c.primary_rays; out->shadow_rays = c.shadow_rays;
     out->slab_tests = c.slab_tests; out->tri_tests = c.tri_tests;
     out->hit_pixels = c.hit_pixels; out->shadowed_pixels = c.shadowed_pixels;
-    out->skip_checks = c.checks;
+    out->skip_checks = c.checks; out->idle_shadow_rays = c.idle_shadow;
     out->vis_disagreements = c.bad_vis; out->shadow_vis_disagreements = c.bad_shadow_vis;
     out->entry_disagreements = c.bad_entry; out->cull_disagreements = c.bad_cull; out->instance_disagreements = c.bad_inst;
     return RT_OK;

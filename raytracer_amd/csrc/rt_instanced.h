@@ -172,6 +172,7 @@ RT_HD InstancedOut shade_instanced_pixel(const FrameArgs& A, const InstancedArgs
     // and the shadow ray is not sent (shade_pixel does the same)
     const float facing = dot(n, L);
     const bool unsent = colour_only && !COUNT && !Party::kVerify && !(facing > 0.2f);
+    if (COUNT && !(facing > 0.2f)) work.idle++;
     if (!unsent) walk.begin(I, so, recip(L), tstack);
     while (!dark && !unsent) {
         MeshArgs W;

@@ -64,7 +64,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 }
 
 struct LaneTotals {
-    unsigned long long pixels, hits, darks, slabs, tris;
+    unsigned long long pixels, hits, darks, slabs, tris, idle;
 };
 
 // What a self-checking launch (RT_FLAG_VERIFY_SKIPS) found, summed over the wave; one atomic per wave and counter.
@@ -83,8 +83,9 @@ __device__ __forceinline__ void flush_checks(DeviceCounters* c, const Work& w) {
 
 __device__ __forceinline__ void flush_counters(DeviceCounters* c, const LaneTotals& t) {
     const unsigned long long prim = wave_sum(t.pixels), hit = wave_sum(t.hits), dark = wave_sum(t.darks);
-    const unsigned long long slabs = wave_sum(t.slabs), tris = wave_sum(t.tris);
+    const unsigned long long slabs = wave_sum(t.slabs), tris = wave_sum(t.tris), idle = wave_sum(t.idle);
     if ((threadIdx.x & 63) == 0) {
+        if (idle) atomicAdd(&c->idle_shadow, idle);
         atomicAdd(&c->primary_rays, prim);
         atomicAdd(&c->shadow_rays, hit);
         atomicAdd(&c->hit_pixels, hit);
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const 
     tile_pixel(tile, threadIdx.x & 63, tiles_x, px, py);
     const bool active = px < A.width && py < A.height;
 
-    LaneTotals tot = {0, 0, 0, 0, 0};
+    LaneTotals tot = {0, 0, 0, 0, 0, 0};
     const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
     Work work;
     if (active) {
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(BLOCK) render_direct(const FrameArgs A, const 
         if (VERIFY) r = shade_pixel<COUNT, FULL, false>(A, nodes, SoloVerify(), px, py, stack, work);
         else r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work, O.shadow == nullptr);
         store_pixel(O, A.width, px, py, r);
-        tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
+        tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris; tot.idle = work.idle;
     }
     if (O.tile_clock && (threadIdx.x & 63) == 0 && tile < tiles_x * ((A.height + 7) >> 3)) {
         O.tile_clock[2 * (size_t)tile] = t_start;
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(BLOCK, VERIFY ? 1 : 7) render_sampled(const Fr
     const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     int px, py;
     tile_pixel(tile, threadIdx.x & 63, tiles_x, px, py);
-    LaneTotals tot = {0, 0, 0, 0, 0};
+    LaneTotals tot = {0, 0, 0, 0, 0, 0};
     Work work;
     if (px < A.width && py < A.height) {
         SampledOut r;
@@ -168,14 +169,15 @@ __global__ void __launch_bounds__(BLOCK, VERIFY ? 1 : 7) render_sampled(const Fr
         uint8_t* rgb = O.rgb + p * 3;
         rgb[0] = r.r; rgb[1] = r.g; rgb[2] = r.b;
         if (O.hit_id) O.hit_id[p] = r.hit_id;
-        tot.pixels = (unsigned long long)X.spp; tot.hits = r.hits; tot.darks = r.darks; tot.slabs = work.slabs; tot.tris = work.tris;
+        tot.pixels = (unsigned long long)X.spp; tot.hits = r.hits; tot.darks = r.darks; tot.slabs = work.slabs; tot.tris = work.tris; tot.idle = work.idle;
     }
     if (VERIFY) flush_checks(O.counters, work);
     if (COUNT || VERIFY) {
         // shadow rays = hit samples x lights
         const unsigned long long prim = wave_sum(tot.pixels), hit = wave_sum(tot.hits), dark = wave_sum(tot.darks);
-        const unsigned long long slabs = wave_sum(tot.slabs), tris = wave_sum(tot.tris);
+        const unsigned long long slabs = wave_sum(tot.slabs), tris = wave_sum(tot.tris), idle = wave_sum(tot.idle);
         if ((threadIdx.x & 63) == 0) {
+            if (idle) atomicAdd(&O.counters->idle_shadow, idle);
             atomicAdd(&O.counters->primary_rays, prim);
             atomicAdd(&O.counters->shadow_rays, hit * (unsigned long long)X.n_lights);
             atomicAdd(&O.counters->hit_pixels, hit);
@@ -209,7 +211,7 @@ __global__ void __launch_bounds__(64 * kSplitWaves) render_sampled_split(const F
     int px, py;
     tile_pixel(tile, lane, tiles_x, px, py);
     const bool inside = px < A.width && py < A.height;
-    LaneTotals tot = {0, 0, 0, 0, 0};
+    LaneTotals tot = {0, 0, 0, 0, 0, 0};
     SampledOut out;
     out.hits = 0; out.darks = 0; out.hit_id = -1;
     Work work; work.slabs = 0; work.tris = 0;
@@ -241,10 +243,11 @@ __global__ void __launch_bounds__(64 * kSplitWaves) render_sampled_split(const F
         tot.pixels = (unsigned long long)X.spp; tot.hits = hits; tot.darks = darks;
     }
     if (COUNT) {
-        tot.slabs = work.slabs; tot.tris = work.tris;
+        tot.slabs = work.slabs; tot.tris = work.tris; tot.idle = work.idle;
         const unsigned long long prim = wave_sum(tot.pixels), hit = wave_sum(tot.hits), dark = wave_sum(tot.darks);
-        const unsigned long long slabs = wave_sum(tot.slabs), tris = wave_sum(tot.tris);
+        const unsigned long long slabs = wave_sum(tot.slabs), tris = wave_sum(tot.tris), idle = wave_sum(tot.idle);
         if (lane == 0) {
+            if (idle) atomicAdd(&O.counters->idle_shadow, idle);
             if (wave == 0) {
                 atomicAdd(&O.counters->primary_rays, prim);
                 atomicAdd(&O.counters->shadow_rays, hit * (unsigned long long)X.n_lights);
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(BLOCK, VERIFY ? 1 : 5) render_instanced(const 
     const int tile = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     int px, py;
     tile_pixel(tile, threadIdx.x & 63, tiles_x, px, py);
-    LaneTotals tot = {0, 0, 0, 0, 0};
+    LaneTotals tot = {0, 0, 0, 0, 0, 0};
     Work work;
     if (px < A.width && py < A.height) {
         InstancedOut r;
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(BLOCK, VERIFY ? 1 : 5) render_instanced(const 
         if (hit_tri) hit_tri[p] = r.tri;
         if (O.hit_t) O.hit_t[p] = r.hit_t;
         if (O.shadow) O.shadow[p] = r.shadow;
-        tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
+        tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris; tot.idle = work.idle;
     }
     if (COUNT || VERIFY) flush_counters(O.counters, tot);
     if (VERIFY) flush_checks(O.counters, work);
@@ -787,7 +790,7 @@ __global__ void __launch_bounds__(BLOCK) render_tiles(const FrameArgs A, const S
     const int tiles_x = (A.width + 7) >> 3, tiles_y = (A.height + 7) >> 3;
     int wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const unsigned long long t_start = O.tile_clock ? wall_clock64() : 0ull;
-    LaneTotals tot = {0, 0, 0, 0, 0};
+    LaneTotals tot = {0, 0, 0, 0, 0, 0};
     int tile = -1;
 
     // Wave index space: [rect 0: 8 waves per tile][rect 1] ... [all tiles, one wave each].
@@ -835,7 +838,7 @@ __global__ void __launch_bounds__(BLOCK) render_tiles(const FrameArgs A, const S
             Work work; work.slabs = 0; work.tris = 0;
             const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work, O.shadow == nullptr);
             store_pixel(O, A.width, px, py, r);
-            tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris;
+            tot.pixels = 1; tot.hits = r.hit; tot.darks = r.dark; tot.slabs = work.slabs; tot.tris = work.tris; tot.idle = work.idle;
         }
     }
     if (O.tile_clock && lane == 0 && tile >= 0) {
@@ -991,7 +994,7 @@ __global__ void __launch_bounds__(kResidentBlock) render_resident(const FrameArg
 
     const int lane = threadIdx.x & 63;
     const int tiles_x = (A.width + 7) >> 3;
-    LaneTotals tot = {0, 0, 0, 0, 0};
+    LaneTotals tot = {0, 0, 0, 0, 0, 0};
 
     auto do_tile = [&](int tile) {
         int px, py;
@@ -1001,7 +1004,7 @@ __global__ void __launch_bounds__(kResidentBlock) render_resident(const FrameArg
             Work work; work.slabs = 0; work.tris = 0;
             const PixelOut r = shade_pixel<COUNT, FULL, false>(A, nodes, Solo(), px, py, stack, work, O.shadow == nullptr);
             store_pixel(O, A.width, px, py, r);
-            if (COUNT) { tot.pixels += 1; tot.hits += r.hit; tot.darks += r.dark; tot.slabs += work.slabs; tot.tris += work.tris; }
+            if (COUNT) { tot.pixels += 1; tot.hits += r.hit; tot.darks += r.dark; tot.slabs += work.slabs; tot.tris += work.tris; tot.idle += work.idle; }
         }
         if (O.tile_clock && lane == 0) {
             O.tile_clock[2 * (size_t)tile] = t_start;

@@ -174,6 +174,7 @@ struct DeviceCounters {          // accumulated with atomics when counting is re
     unsigned long long primary_rays, shadow_rays, slab_tests, tri_tests, hit_pixels, shadowed_pixels;
     // self-checking launches (RT_FLAG_VERIFY_SKIPS): see Work in rt_pixel.h
     unsigned long long checks, bad_vis, bad_shadow_vis, bad_entry, bad_cull, bad_inst;
+    unsigned long long idle_shadow;  // shadow rays (part of shadow_rays) whose result cannot change the colour: see Work::idle
 };
 
 // Scene-wide device data (valid for every frame until the meshes change).

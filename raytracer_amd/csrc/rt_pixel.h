@@ -36,6 +36,7 @@ RT_HD Hit no_hit() { Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; h.prio = 0; re
 
 struct Work {
     uint32_t slabs = 0, tris = 0;
+    uint32_t idle = 0;           // counting runs: shadow rays sent although their result cannot change the colour (max(0.2, n.L) = 0.2)
     // Filled by the self-checking party only (SoloVerify): shortcut decisions that were examined again the reference's way,
     // and how many of them the reference's way contradicts, by kind.
     uint32_t checks = 0;
@@ -625,6 +626,7 @@ RT_HD PixelOut shade_pixel(const FrameArgs& A, const Nodes& nodes, const Party& 
     const float facing = dot(n, L);
     const bool unsent = colour_only && !COUNT && !FULL && !Party::kVerify && !(facing > 0.2f);   // a NaN compares false: fmaxf(0.2f, NaN) is 0.2f as well
     const int n_shadow = unsent ? 0 : A.n_mesh;
+    if (COUNT && !(facing > 0.2f)) work.idle++;
     for (int m = 0; m < n_shadow && !dark; m++) {
         const MeshArgs& S = A.mesh[m];
         // outside A.vis_shadow[m] no surface point seen in this tile can send its shadow ray through the mesh's root box

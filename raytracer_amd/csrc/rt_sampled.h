@@ -109,6 +109,7 @@ RT_HD F3 sample_value(const FrameArgs& A, const SampleArgs& X, const Nodes& node
             // already, scene.c:143-144 gives 0.2 blocked or not, and the shadow ray towards this light is not sent.
             const float facing = dot(n, f3(X.light_dir[l]));
             const int n_shadow = (!COUNT && !Party::kVerify && !(facing > 0.2f)) ? 0 : A.n_mesh;
+            if (COUNT && !(facing > 0.2f)) work.idle++;
             for (int m = 0; m < n_shadow && !dark; m++) {
                 const MeshArgs& S = A.mesh[m];
                 const F3 lo = S.w_mode == 2 ? xform_point_w1(S.inv, so) : xform_point(S.inv, S.wrow, so);

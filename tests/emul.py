@@ -32,7 +32,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("primary_rays", "shadow_rays", "slab_tests", "tri_tests", "hit_pixels", "shadowed_pixels", "skip_checks",
                  "vis_disagreements", "shadow_vis_disagreements", "entry_disagreements", "cull_disagreements",
-                 "instance_disagreements")]
+                 "instance_disagreements", "idle_shadow_rays")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

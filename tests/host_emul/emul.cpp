@@ -48,12 +48,13 @@ struct EmulScene {
     int hierarchy_reused = 0;          // calls that reused the kept tree
 };
 struct CheckTotals {
-    unsigned long long checks = 0, vis = 0, shadow_vis = 0, entry = 0, cull = 0, inst = 0;
-    void add(const Work& w) { checks += w.checks; vis += w.bad_vis; shadow_vis += w.bad_shadow_vis; entry += w.bad_entry; cull += w.bad_cull; inst += w.bad_inst; }
-    void merge(const CheckTotals& o) { checks += o.checks; vis += o.vis; shadow_vis += o.shadow_vis; entry += o.entry; cull += o.cull; inst += o.inst; }
+    unsigned long long checks = 0, vis = 0, shadow_vis = 0, entry = 0, cull = 0, inst = 0, idle = 0;
+    void add(const Work& w) { idle += w.idle; checks += w.checks; vis += w.bad_vis; shadow_vis += w.bad_shadow_vis; entry += w.bad_entry; cull += w.bad_cull; inst += w.bad_inst; }
+    void merge(const CheckTotals& o) { idle += o.idle; checks += o.checks; vis += o.vis; shadow_vis += o.shadow_vis; entry += o.entry; cull += o.cull; inst += o.inst; }
     void store(rt_counters* c) const {
         c->skip_checks = checks; c->vis_disagreements = vis; c->shadow_vis_disagreements = shadow_vis;
         c->entry_disagreements = entry; c->cull_disagreements = cull; c->instance_disagreements = inst;
+        c->idle_shadow_rays = idle;
     }
 };
 }  // namespace

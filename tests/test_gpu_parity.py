@@ -128,6 +128,20 @@ def test_work_counters_match_reference_traversal(capi, ctx, po, meshes):
     c = ctx.last_counters()
     assert c["primary_rays"] == want.counters["primary_rays"] and c["shadow_rays"] == want.counters["shadow_rays"]
     assert c["slab_tests"] <= want.counters["slab_tests"] and c["tri_tests"] <= want.counters["tri_tests"]
+    # shadow rays that start on a surface turned away from the light (max(0.2, n.L) = 0.2): counted here, not sent by calls
+    # that store the colour only; the same number in both traversal modes, and what the host build of the pixel code counts
+    import emul
+    assert c["idle_shadow_rays"] == got_idle_reference_order(ctx, capi, cam, light, tfs) and 0 < c["idle_shadow_rays"] < c["shadow_rays"]
+    s = emul.Scene(regroup=True)
+    for m in meshes:
+        assert s.add(m.tris, m.nodes, m.rgba) == 0
+    assert s.render(po.default_camera(), po.default_light(), tfs, 320, 180)["counters"]["idle_shadow_rays"] == c["idle_shadow_rays"]
+    s.close()
+
+
+def got_idle_reference_order(ctx, capi, cam, light, tfs):
+    ctx.render_host(cam, light, to_capi_tfs(capi, tfs), 320, 180, flags=capi.RT_FLAG_COUNT_WORK | capi.RT_FLAG_REFERENCE_ORDER)
+    return ctx.last_counters()["idle_shadow_rays"]
 
 
 def test_all_kernel_variants_agree(capi, ctx, po, golden_frames):

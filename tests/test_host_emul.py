@@ -626,6 +626,8 @@ def test_shadow_rays_that_cannot_change_the_colour_are_left_out_without_changing
         assert np.array_equal(got["shadow"][sent], want.shadow[sent])            # the rays that were sent end as the oracle's
         assert ((got["hit_id"] >> 24)[~sent] != 2).all()                         # the ground faces the light: all of its rays go out
         unsent += int((~sent).sum())
+        counted = em_default.render(po.default_camera(), po.default_light(), tfs, 240, 135)["counters"]
+        assert counted["idle_shadow_rays"] == int((~sent).sum())                 # a counting run sends them, and says how many
     assert unsent > 500
     rng = np.random.default_rng(17)
     for _ in range(8):
