@@ -203,7 +203,7 @@ int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tr
         dm.d_tris = t; dm.d_attrs = a;
     }
     if (dm.d_grid) { (void)hipFree(dm.d_grid); dm.d_grid = nullptr; }
-    if (pk.grid_axis < 3) {
+    if (pk.grid_axis != 3) {
         const int gst = upload_array(ctx, pk.grid, &dm.d_grid);
         if (gst != RT_OK) return gst;
     }
@@ -378,6 +378,7 @@ void enter_loose_tree(const DeviceMesh& dm, MeshArgs& M) {
     M.pair_count = dm.loose_pairs;
     M.tris = dm.d_loose_tris;
     M.res_pairs = M.res_tris = kNotResident;
+    if (M.grid_axis >= 4u) { M.grid_axis = 3u; M.grid = nullptr; }      // the sheared tree's records name the reference's leaves
 }
 
 // Per-frame constants: camera basis, light, and each mesh's placement (inverse matrices, camera

@@ -86,6 +86,12 @@ struct MeshArgs {
     // Where the reference's own tree starts when root_ref enters a regrouped one (rt_pack.h, Packer::regroup);
     // equal to root_ref otherwise.  Same index space as root_ref (relative to pair_base).
     uint32_t ref_root;
+    // grid_axis = 4 + k: a further tree over the reference's leaves, in the same node array, whose boxes live in a sheared frame
+    // (axis k kept; of the other two, a = (k + 1) % 3 and b = (k + 2) % 3, the frame's coordinates are p_a + p_b and p_a - p_b),
+    // where beams that run along the diagonals of a and b get tight boxes.  Its leaves are records like the flat grid's lists
+    // (kGridListBit); `grid` then holds a header, the directions a ray must keep away from to enter this tree, and the records
+    // (ShearHeader, Packer::build_shear).
+    uint32_t shear_root;
     // Flat meshes (root box of zero thickness along grid_axis, e.g. a ground plane): a grid over the other two axes whose
     // cells name the node of the tree behind root_ref at which a ray that meets the mesh's plane inside the cell may start
     // its walk -- everything above that node has, for such a ray, exactly one child whose box it can pass (FlatGrid in
@@ -101,7 +107,19 @@ struct MeshArgs {
 // bit, a list of leaves: bits 27..24 = count (1..kGridListMax), bits 23..0 = first record; the records (eight words each: leaf
 // box min, max, leaf reference, mask of the leaf's triangles to test) follow the grid_n * grid_n cell words, rounded up to a
 // multiple of eight words.
+static_assert(sizeof(MeshArgs) == 280, "MeshArgs: the staging arrays of per-frame constants are sized by it");
 constexpr uint32_t kGridListBit = 0x40000000u;
+// MeshArgs::grid of a mesh with a sheared tree, in words: this header (16 words), then MeshArgs::grid_n directions of four
+// floats (unit normal of a family of the mesh's triangles, and how large |d . n| must at least be), then, from the next multiple
+// of eight words on, one record per leaf of the reference's tree (as the flat grid's list records: box min, max, leaf, mask).
+struct ShearHeader {
+    float reach;             // a ray enters the sheared tree only if |o| <= reach ...
+    float origin_factor;     // ... and o lies outside [hull_min, hull_max] widened by origin_factor * (|o| + radius)
+    float radius;            // largest |vertex|
+    float hull_min[3], hull_max[3];
+    float pad[7];
+};
+static_assert(sizeof(ShearHeader) == 64, "ShearHeader is sixteen words");
 constexpr uint32_t kGridListMax = 8;
 constexpr uint32_t kNotResident = 0xFFFFFFFFu;
 // Small meshes (nodes + triangles) are copied into LDS by every workgroup of the lean kernels, the

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <future>
 #include <map>
@@ -152,13 +153,18 @@ struct PackedMesh {
     uint32_t loose_pairs = 0;
     int loose_depth = 0;
     std::vector<TriRec> loose_tris;
+    // A tree over the reference's leaves in a sheared frame (Packer::build_shear): grid_axis = 4 + kept axis, `grid` holds its
+    // header, directions (grid_n of them) and leaf records; shear_root enters it.
+    uint32_t shear_root = kLeafBit;
+    uint32_t shear_pairs = 0;
 };
 
 // The grid fields of a MeshArgs from a packed mesh; d_grid = where pk.grid lives for the code that will traverse.
 inline void set_grid_args(const PackedMesh& pk, const uint32_t* d_grid, MeshArgs& M) {
-    M.grid = pk.grid_axis < 3 ? d_grid : nullptr;
+    M.grid = pk.grid_axis != 3 ? d_grid : nullptr;
     M.grid_axis = M.grid ? pk.grid_axis : 3u;
     M.grid_n = pk.grid_n;
+    M.shear_root = pk.shear_root;
     for (int j = 0; j < 2; j++) { M.grid_lo[j] = pk.grid_lo[j]; M.grid_inv[j] = pk.grid_inv[j]; M.grid_slack[j] = pk.grid_slack[j]; M.grid_bmax[j] = pk.grid_bmax[j]; }
 }
 
@@ -207,6 +213,7 @@ public:
         if (regroup_) build_grid();
         out_.loose_root = out_.root_ref; out_.loose_pairs = out_.tree_pairs;
         if (regroup_ && out_.grid_axis == 3) build_loose();
+        if (regroup_ && out_.grid_axis == 3) build_shear();
         return RT_OK;
     }
 
@@ -516,6 +523,198 @@ private:
         out_.loose_root = root + shift;
         out_.loose_pairs = (uint32_t)loose.size();
         out_.loose_depth = deepest;
+        if (deepest > out_.depth) out_.depth = deepest;
+    }
+
+    // ---- a tree in a sheared frame ---------------------------------------------------------------------
+    // Axis-aligned boxes are the worst fit for long thin triangles that run along a diagonal: the box of a beam from
+    // (-1, -1) to (1, 1) is the whole square, and a ray anywhere through the square tests every triangle of every such beam
+    // (the reference scene's drone: 109 triangle tests per ray through its root box, nine in ten of all triangle tests of
+    // a frame).  In the frame (p_a + p_b, p_a - p_b, p_k) those beams are axis-aligned.  This builds a further tree over the
+    // reference's leaves whose boxes live in that frame and are walked with the sheared ray (rt_pixel.h: shear, trace_mesh);
+    // a leaf of it is a record that holds the reference's own box of that leaf, which is tested the reference's way before
+    // the leaf's triangles are.
+    //
+    // What the tree must promise: a ray that the reference's triangle test (ray.c:42-67, float) accepts on triangle i, after
+    // passing the reference's box of i's leaf, reaches that leaf's record.  The boxes above a record contain its box and the
+    // slab arithmetic is monotone (see regroup), so it is enough that the ray passes the record's own box, and that is
+    // arranged as follows.  u = 2^-24, the ray o + t d with |d| = 1, s = o - v0, S >= |s|, a = e1 . (d x e2) = -d . N with
+    // N = e1 x e2, |a| = |N| |cos| where cos = d . N / |N|.  In floats every one of a, U = s . (d x e2), V = d . (s x e1),
+    // T = e2 . (s x e1) is a triple product whose computed value is off by at most 11 u times the product of the three
+    // lengths (three roundings per cross component, three per dot, one for s); the code below takes 12 u and doubles every
+    // bound once more.  With |cos| >= c:
+    //   * the computed a has the sign of the true one and at least three quarters of its size as soon as
+    //     24 u |e1| |e2| <= |N| c / 4;
+    //   * the ray meets the triangle's plane in X = v0 + u* e1 + v* e2; u* < -eps_u with eps_u = 24 u S |e2| / (|N| c) makes
+    //     the computed U carry the sign that gives u < 0 (ray.c:56), likewise v* < -eps_v with |e1| (ray.c:61), and u* + v* >
+    //     1 + eps_3, eps_3 = 24 u (|e1| |e2| + S (|e1| + |e2|)) / (|N| c) + 8 u, makes the computed u + v exceed 1 (ray.c:61):
+    //     the triangle test accepts only if X lies in the triangle widened by those three amounts;
+    //   * the computed t differs from X's parameter t* by at most 24 u S |e1| |e2| / (|N| c); an accepted t is positive
+    //     (ray.c:66), so either t* > 0 or the origin lies within that distance of X.
+    // The box of a record is the box, in the sheared frame, of its triangles widened like that (with S = the largest |o| +
+    // |vertex| a ray may have to enter the tree, c = the triangle's own bound), plus room for the rounding of the sheared ray
+    // and of the slab test; a ray enters the tree only if it keeps |cos| >= c for every triangle of the mesh and starts
+    // outside the hull of all widened triangles by more than the last distance (shear_gate).  For such a ray t* > 0, X lies on
+    // the ray inside the record's box with that room to spare, and the slab test passes.  c is the smallest bound that keeps
+    // the widening small as a distance: a hundred-and-twenty-eighth of the mesh's radius across the two edges at v0, one radius along
+    // the triangle's own edges (where a needle's widening goes).  Triangles whose bound c would have
+    // to exceed 1/16 (needle-thin beyond what the drone has, or of no area) make the mesh keep its other trees only; so does a
+    // mesh whose triangles face too many different ways to list, or whose boxes the frame does not shrink by half.
+    static constexpr double kShearGrowth = 1.0;        // how far along its own edges a widened triangle may grow, in radii of the mesh
+    static constexpr double kShearCosMax = 1.0 / 16.0, kShearCosMin = 1.0 / 1024.0;
+    static constexpr double kShearBeyond = 8.0;        // rays may start this far outside the mesh's radius
+    static constexpr size_t kShearMaxDirections = 64;
+    static constexpr double kShearAngle = 1.0 / 512.0;      // triangles whose normals differ by less share a direction
+
+    static void shear_point(const double* p, int k, double* out) {
+        if (k == 0) { out[0] = p[0]; out[1] = p[1] + p[2]; out[2] = p[1] - p[2]; }
+        else if (k == 1) { out[0] = p[2] - p[0]; out[1] = p[1]; out[2] = p[2] + p[0]; }
+        else { out[0] = p[0] + p[1]; out[1] = p[0] - p[1]; out[2] = p[2]; }
+    }
+    static float round_down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -INFINITY) : f; }
+    static float round_up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; }
+
+    void build_shear() {
+        if (out_.empty || out_.tris.empty() || !leaves_ok_ || leaves_.size() < 8 || leaves_.size() >= ((size_t)1 << 23) || (out_.root_ref & kLeafBit)) return;
+        const double U = std::ldexp(1.0, -24);
+        double radius = 0.0;
+        for (const TriRec& t : out_.tris)
+            for (int c = 0; c < 3; c++) {
+                double v[3];
+                for (int a = 0; a < 3; a++) v[a] = (double)t.v0[a] + (c == 1 ? (double)t.e1[a] : (c == 2 ? (double)t.e2[a] : 0.0));
+                const double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                if (!(len <= 1e15)) return;                                  // NaN, infinite or huge: the other trees only
+                radius = len > radius ? len : radius;
+            }
+        if (!(radius >= 1e-6)) return;
+        const double S = radius + kShearBeyond;
+        const double pad_uv = radius / 128.0;              // how far outside the two edges at v0 a widened triangle may reach at most
+        struct Widened { double corner[3][3]; };
+        std::vector<Widened> widened(out_.tris.size());
+        struct Direction { double n[3]; double c; };
+        std::vector<Direction> directions;
+        double origin_factor = 0.0;
+        double hull_lo[3] = {1e300, 1e300, 1e300}, hull_hi[3] = {-1e300, -1e300, -1e300};
+        for (const LeafItem& leaf : leaves_) {
+            const uint32_t first = leaf.ref & 0x00FFFFFFu, count = (leaf.ref >> 24) & 0x7Fu;
+            for (uint32_t i = first; i < first + count; i++) {
+                if (i >= out_.tris.size()) return;
+                const TriRec& t = out_.tris[i];
+                const double v0[3] = {t.v0[0], t.v0[1], t.v0[2]}, e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]};
+                const double N[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                const double n2 = std::sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+                const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+                if (!(n2 > 0.0) || !(l1 > 1e-9) || !(l2 > 1e-9)) return;
+                const double q = l1 * l2 / n2, p = (l1 + l2) / n2;
+                double c = kShearCosMin;
+                c = std::max(c, 96.0 * U * q);                                                   // the sign and size of a
+                c = std::max(c, 24.0 * U * S / pad_uv);                                          // eps_u, eps_v as distances
+                const double longest = l1 > l2 ? l1 : l2;
+                c = std::max(c, 24.0 * U * (q + S * p) * longest / (kShearGrowth * radius - 8.0 * U * longest));   // eps_3 as a distance
+                c = std::max(c, 24.0 * U * S * q / (kShearGrowth * radius));                     // eps_u, eps_v along the edges
+                if (!(c <= kShearCosMax)) return;
+                const double eps_u = 24.0 * U * S * l2 / (n2 * c), eps_v = 24.0 * U * S * l1 / (n2 * c);
+                const double eps_3 = 24.0 * U * (q + S * p) / c + 8.0 * U;
+                origin_factor = std::max(origin_factor, 24.0 * U * q / c);
+                const double bary[3][2] = {{-eps_u, -eps_v}, {1.0 + eps_3 + eps_v, -eps_v}, {-eps_u, 1.0 + eps_3 + eps_u}};
+                for (int k = 0; k < 3; k++)
+                    for (int a = 0; a < 3; a++) {
+                        widened[i].corner[k][a] = v0[a] + bary[k][0] * e1[a] + bary[k][1] * e2[a];
+                        hull_lo[a] = std::min(hull_lo[a], widened[i].corner[k][a]); hull_hi[a] = std::max(hull_hi[a], widened[i].corner[k][a]);
+                    }
+                // the direction family of this triangle: an existing one within kShearAngle, or a new one
+                const double unit_n[3] = {N[0] / n2, N[1] / n2, N[2] / n2};
+                bool found = false;
+                for (Direction& dir : directions) {
+                    const double along = unit_n[0] * dir.n[0] + unit_n[1] * dir.n[1] + unit_n[2] * dir.n[2];
+                    const double sgn = along < 0.0 ? -1.0 : 1.0;
+                    const double off[3] = {unit_n[0] - sgn * dir.n[0], unit_n[1] - sgn * dir.n[1], unit_n[2] - sgn * dir.n[2]};
+                    const double away = std::sqrt(off[0] * off[0] + off[1] * off[1] + off[2] * off[2]);
+                    if (away <= kShearAngle) { dir.c = std::max(dir.c, c + away); found = true; break; }   // |d . n_i| >= |d . n| - |n_i - n|
+                }
+                if (!found) {
+                    if (directions.size() >= kShearMaxDirections) return;
+                    Direction dir; dir.n[0] = unit_n[0]; dir.n[1] = unit_n[1]; dir.n[2] = unit_n[2]; dir.c = c;
+                    directions.push_back(dir);
+                }
+            }
+        }
+        // room for the rounding of the sheared origin and direction and of the slab arithmetic on coordinates of up to 2 S
+        const double room = S / 8192.0;
+        // the frame that shrinks the leaves' boxes most, measured by the surface of the boxes as they lie in the mesh's own space
+        int best_k = -1;
+        double best_area = 0.0, plain_area = 0.0;
+        for (const LeafItem& leaf : leaves_) plain_area += (double)half_area(leaf.lo, leaf.hi);
+        std::vector<LeafItem> items(leaves_.size()), best_items;
+        for (int k = 0; k < 3; k++) {
+            double area = 0.0;
+            for (size_t j = 0; j < leaves_.size(); j++) {
+                const uint32_t first = leaves_[j].ref & 0x00FFFFFFu, count = (leaves_[j].ref >> 24) & 0x7Fu;
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for (uint32_t i = first; i < first + count; i++)
+                    for (int c = 0; c < 3; c++) {
+                        double g[3];
+                        shear_point(widened[i].corner[c], k, g);
+                        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], g[a]); hi[a] = std::max(hi[a], g[a]); }
+                    }
+                for (int a = 0; a < 3; a++) { items[j].lo[a] = round_down(lo[a] - room); items[j].hi[a] = round_up(hi[a] + room); }
+                items[j].ref = kGridListBit | (1u << 24) | (uint32_t)j;
+                // sides of the box in the mesh's space: the two sheared coordinates stretch lengths by sqrt(2)
+                double side[3];
+                for (int a = 0; a < 3; a++) side[a] = (double)items[j].hi[a] - (double)items[j].lo[a];
+                const int kept = k == 0 ? 0 : (k == 1 ? 1 : 2);
+                for (int a = 0; a < 3; a++) if (a != kept) side[a] /= std::sqrt(2.0);
+                area += side[0] * side[1] + side[1] * side[2] + side[2] * side[0];
+            }
+            if (best_k < 0 || area < best_area) { best_k = k; best_area = area; best_items = items; }
+        }
+        if (!(best_area <= 0.5 * plain_area)) return;
+        if (out_.pairs.size() + leaves_.size() >= (size_t)kGridListBit) return;
+        // records, in the order of leaves_ as it stands now; the tree is built over copies that regroup_range may reorder
+        std::vector<LeafItem> records = leaves_;
+        leaves_.swap(best_items);
+        int balanced = 1;
+        while (((size_t)1 << balanced) < leaves_.size()) balanced++;
+        depth_cap_ = out_.depth > balanced ? out_.depth : balanced + 1;
+        if (depth_cap_ > RT_MAX_TREE_DEPTH) depth_cap_ = RT_MAX_TREE_DEPTH;
+        std::vector<PairNode> tree(leaves_.size() - 1);
+        int deepest = 0;
+        float lo[3], hi[3];
+        const uint32_t root = regroup_range(tree, 0, 0, leaves_.size(), 0, deepest, lo, hi);
+        depth_cap_ = RT_MAX_TREE_DEPTH;
+        leaves_.swap(records);                                              // leaves_ as before; `records` is scratch from here on
+        if ((root & (kLeafBit | kGridListBit)) || deepest + 2 > kStackDepth || deepest > RT_MAX_TREE_DEPTH) return;
+        const uint32_t shift = (uint32_t)out_.pairs.size();
+        for (PairNode p : tree) {
+            if (!(p.lref & (kLeafBit | kGridListBit))) p.lref += shift;
+            if (!(p.rref & (kLeafBit | kGridListBit))) p.rref += shift;
+            out_.pairs.push_back(p);
+        }
+        // header, directions, records
+        const size_t n_dir = directions.size();
+        const size_t rec_base = ((size_t)16 + 4 * n_dir + 7) & ~(size_t)7;
+        out_.grid.assign(rec_base + 8 * leaves_.size(), 0u);
+        ShearHeader header;
+        memset(&header, 0, sizeof header);
+        header.reach = round_down(kShearBeyond);
+        header.origin_factor = round_up(origin_factor * 1.0001);
+        header.radius = round_up(radius);
+        for (int a = 0; a < 3; a++) { header.hull_min[a] = round_down(hull_lo[a]); header.hull_max[a] = round_up(hull_hi[a]); }
+        memcpy(out_.grid.data(), &header, sizeof header);
+        for (size_t k = 0; k < n_dir; k++) {
+            const float rec[4] = {(float)directions[k].n[0], (float)directions[k].n[1], (float)directions[k].n[2],
+                                  round_up(directions[k].c + 1.0 / 65536.0)};          // the rounding of n and of the dot product
+            memcpy(out_.grid.data() + 16 + 4 * k, rec, 16);
+        }
+        for (size_t j = 0; j < leaves_.size(); j++) {
+            uint32_t* rec = out_.grid.data() + rec_base + 8 * j;
+            memcpy(rec, leaves_[j].lo, 12); memcpy(rec + 3, leaves_[j].hi, 12);
+            rec[6] = leaves_[j].ref; rec[7] = 0xFFFFFFFFu;
+        }
+        out_.grid_axis = 4u + (uint32_t)best_k;
+        out_.grid_n = (int32_t)n_dir;
+        out_.shear_root = root + shift;
+        out_.shear_pairs = (uint32_t)tree.size();
         if (deepest > out_.depth) out_.depth = deepest;
     }
 

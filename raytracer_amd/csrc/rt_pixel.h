@@ -304,6 +304,51 @@ RT_HD uint32_t entry_ref(const MeshArgs& M, F3 d) {
 
 RT_HD float comp(F3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 
+// The sheared frame of MeshArgs::grid_axis = 4 + k (axis k kept; a = (k + 1) % 3, b = (k + 2) % 3 become p_a + p_b and p_a - p_b).
+// Linear, so a ray o + t d maps to shear(o) + t shear(d) with the same t.
+RT_HD F3 shear(F3 p, uint32_t k) {
+    if (k == 0) return f3(p.x, p.y + p.z, p.y - p.z);
+    if (k == 1) return f3(p.z - p.x, p.y, p.z + p.x);
+    return f3(p.x + p.y, p.x - p.y, p.z);
+}
+
+// Four words of a MeshArgs::grid that every lane reads at the same place (header and directions of a sheared tree).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ f32x4 read_uniform4(const uint32_t* base, uint32_t word) {
+    return *(const __attribute__((address_space(4))) f32x4*)((const __attribute__((address_space(4))) char*)base + (size_t)word * 4);
+}
+#else
+struct f32x4 { float x, y, z, w; };
+RT_HD f32x4 read_uniform4(const uint32_t* base, uint32_t word) { f32x4 r; memcpy(&r, base + word, 16); return r; }
+#endif
+
+// First record of the leaf lists in MeshArgs::grid (in words): behind the cells of a flat mesh's grid, or behind the header and
+// the directions of a sheared tree.
+RT_HD size_t list_base(const MeshArgs& M) {
+    if (M.grid_axis < 3u) return (((size_t)M.grid_n * (size_t)M.grid_n) + 7) & ~(size_t)7;
+    return ((size_t)16 + 4 * (size_t)M.grid_n + 7) & ~(size_t)7;
+}
+
+// Whether a ray may walk a mesh's sheared tree (Packer::build_shear states what the tree promises and why these conditions
+// make it hold): origin within reach and outside the widened hull, direction of unit length and at least the stated angle
+// away from the plane of every family of the mesh's triangles.  Every comparison is false for a NaN.
+RT_HD bool shear_gate(const MeshArgs& M, F3 o, F3 d) {
+    const f32x4 h0 = read_uniform4(M.grid, 0), h1 = read_uniform4(M.grid, 4), h2 = read_uniform4(M.grid, 8);
+    const float reach = h0.x, origin_factor = h0.y, radius = h0.z;
+    const float oo = dot(o, o), dd = dot(d, d);
+    if (!(oo <= reach * reach) || !(fabsf(dd - 1.0f) <= 0.0009765625f)) return false;
+    const float wide = origin_factor * (sqrtf(oo) + radius);
+    const bool outside = o.x < h0.w - wide || o.y < h1.x - wide || o.z < h1.y - wide ||
+                         o.x > h1.z + wide || o.y > h1.w + wide || o.z > h2.x + wide;
+    if (!outside) return false;
+    bool ok = true;
+    for (int32_t k = 0; k < M.grid_n; k++) {
+        const f32x4 n = read_uniform4(M.grid, 16u + 4u * (uint32_t)k);
+        ok = ok && fabsf(d.x * n.x + d.y * n.y + d.z * n.z) >= n.w;
+    }
+    return ok;
+}
+
 // Where a ray starts its walk in a flat mesh (MeshArgs::grid, built by Packer::build_grid): the node stored for the cell
 // that holds the point X in which the ray meets the mesh's plane -- if the ray qualifies: all direction components finite
 // and non-zero (the caller checks the zeros), X inside the grid, and the ray's own uncertainty about X (16 u of the
@@ -338,7 +383,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
     Query q;
     if (!begin_query<ANY, COUNT, FULL>(M, o, inv, bound, q, work)) return false;
     stack.clear();
-    const SlabRay sr = slab_ray(o, inv);
+    SlabRay sr = slab_ray(o, inv);
     if (!FULL) {
         // Descend through PairNodes without touching the stack for the nearer child; only the
         // farther child is parked.  The inner loop holds nothing but box tests, the outer step
@@ -355,11 +400,20 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
                 if (!(plane_t > 0.0f) || (CULL && plane_t > q.limit)) return false;
             }
         }
-        if (!(ref & kLeafBit) && (ref & kGridListBit)) {
-            // the cell names its leaves: each one's own box test (the reference reaches a leaf exactly when that passes,
-            // the boxes above contain it), nothing else
-            const uint32_t count = (ref >> 24) & 0xFu;
-            const size_t first = ((((size_t)M.grid_n * (size_t)M.grid_n) + 7) & ~(size_t)7) + (size_t)(ref & 0x00FFFFFFu) * 8;
+        else if (use_grid && M.grid_axis >= 4u && ref == M.root_ref && shear_gate(M, o, d)) {
+            // the tree in the sheared frame: same records, same slab arithmetic, on the sheared ray (same t); its leaves are
+            // lists of one record, whose own box test is the reference's for that leaf
+            const F3 sd = shear(d, M.grid_axis - 4u);
+            if (sd.x != 0.0f && sd.y != 0.0f && sd.z != 0.0f) {
+                sr = slab_ray(shear(o, M.grid_axis - 4u), recip(sd));
+                ref = M.shear_root;
+            }
+        }
+        // A list of leaves (a flat mesh's cell, a leaf of a sheared tree): each one's own box test (the reference reaches a leaf
+        // exactly when that passes, the boxes above contain it), then its triangles.  True when an any-hit query may stop.
+        auto run_list = [&](const uint32_t list) -> bool {
+            const uint32_t count = (list >> 24) & 0xFu;
+            const size_t first = list_base(M) + (size_t)(list & 0x00FFFFFFu) * 8;
             for (uint32_t i = 0; i < count; i++) {
                 float bmin[3], bmax[3];
                 const size_t at = first + (size_t)i * 8;
@@ -378,6 +432,10 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
                 if (CULL && entry > q.limit) continue;
                 if (test_leaf<ANY, COUNT, FULL, LB>(M, nodes, leaf, o, d, q, work, mask)) return true;
             }
+            return false;
+        };
+        if (!(ref & kLeafBit) && (ref & kGridListBit)) {             // the cell of a flat mesh's grid names its leaves: nothing else to do
+            if (run_list(ref)) return true;
             hit = q.hit;
             return q.found;
         }
@@ -401,7 +459,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
                     ref = stack.pop();
                 }
             };
-            while (live && !(ref & kLeafBit)) {
+            while (live && !(ref & (kLeafBit | kGridListBit))) {
                 if (BUDGET && --steps < 0) return false;
 #if defined(__HIP_DEVICE_COMPILE__)
                 // Neighbouring rays mostly walk the same nodes at the same time (two thirds of all node visits happen with every
@@ -421,7 +479,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
             }
             if (live) {
                 if (BUDGET && --steps < 0) return false;
-                if (test_leaf<ANY, COUNT, FULL, LB>(M, nodes, ref, o, d, q, work)) return true;
+                if ((ref & kLeafBit) ? test_leaf<ANY, COUNT, FULL, LB>(M, nodes, ref, o, d, q, work) : run_list(ref)) return true;
                 if (stack.empty()) live = false;
                 else ref = stack.pop();
             }

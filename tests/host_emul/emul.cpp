@@ -120,7 +120,8 @@ int emul_regroup_routes_agree(const rt_triangle* tris, int32_t n_tris, const rt_
     if (Packer(tris, n_tris, nodes, n_nodes, b, false).run(err) != RT_OK) return -1;
     const bool done = Packer::regroup_packed(b);
     // run() may have appended the tree over the triangles themselves (Packer::build_loose), which the other route does not build
-    const size_t a_pairs = a.loose_tris.empty() ? a.pairs.size() : a.pairs.size() - a.loose_pairs;
+    // ... and the tree in a sheared frame (Packer::build_shear) behind it
+    const size_t a_pairs = a.pairs.size() - (a.loose_tris.empty() ? 0 : a.loose_pairs) - a.shear_pairs;
     const bool had = a.root_ref != a.ref_root || a.tree_pairs != (uint32_t)a_pairs;
     if (!done && !had) return 2;
     const bool same_depth = a.depth == b.depth || (!a.loose_tris.empty() && a.depth == a.loose_depth && a.depth > b.depth);
@@ -212,6 +213,7 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root;
         if (s->loose && !E.pk.loose_tris.empty()) { M.root_ref = M.ref_root = E.pk.loose_root; M.tris = E.pk.loose_tris.data(); }
         set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u; M.wide = E.pk.wide ? 1u : 0u;
+        if (s->loose && M.grid_axis >= 4u) { M.grid_axis = 3u; M.grid = nullptr; }
         fill_placement(tfs[m], A, M);
         mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
     }
