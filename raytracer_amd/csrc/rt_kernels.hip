@@ -531,11 +531,11 @@ static hipError_t launch_lean(const FrameArgs& A, const SceneArgs& S, const Outp
 // per-frame constants share the scalar cache).  The per-frame constants come from an array
 // in device memory; the frame index is uniform per wave, so they are read with scalar loads.
 // ------------------------------------------------------------------------------------------
-// Eight waves per SIMD (the most a SIMD holds) where the short stack leaves room in LDS.  The kernel's vector pipes are
-// saturated and its lanes wait on dependent loads; every further wave hides more of that: per launch of 8 frames, with two
-// triangles fetched per leaf batch (71 registers) six waves 1.023 ms, seven 0.979, eight 0.970 with 28 bytes of scratch; with one
-// triangle per batch (59 registers, nothing spilled) eight waves 0.935 ms, the fast build 0.870.
-constexpr int kBatchWaves = 8;
+// Waves per SIMD the register allocation has to admit.  Measured per launch of 8 frames: with two triangles fetched per leaf
+// batch (71 registers) six waves 1.023 ms, seven 0.979, eight 0.970 with 28 bytes of scratch; with one triangle per batch (59
+// registers, nothing spilled) eight waves 0.935 ms.  Since the walk can enter a mesh's sheared tree (rt_pixel.h) eight waves
+// need 40 bytes of scratch per lane: eight 0.628 ms, seven (72 registers, nothing spilled) 0.607, six 0.614.
+constexpr int kBatchWaves = 7;
 template <int BLOCK, int DEPTH, uint32_t LB>
 __global__ void __launch_bounds__(BLOCK, DEPTH <= 16 ? kBatchWaves : 5) render_batch(const FrameArgs* __restrict__ frames, const int n_frames, const SceneArgs S,
                                                       uint8_t* __restrict__ rgb_base, const unsigned long long frame_stride,

@@ -109,15 +109,19 @@ struct MeshArgs {
 // multiple of eight words.
 static_assert(sizeof(MeshArgs) == 280, "MeshArgs: the staging arrays of per-frame constants are sized by it");
 constexpr uint32_t kGridListBit = 0x40000000u;
-// MeshArgs::grid of a mesh with a sheared tree, in words: this header (16 words), then MeshArgs::grid_n directions of four
-// floats (unit normal of a family of the mesh's triangles, and how large |d . n| must at least be), then, from the next multiple
-// of eight words on, one record per leaf of the reference's tree (as the flat grid's list records: box min, max, leaf, mask).
+// MeshArgs::grid of a mesh with a sheared tree, in words: this header (16 words); MeshArgs::grid_n families of the mesh's
+// triangles, eight words each (unit normal, how large |d . n| must at least be for the tree's boxes to hold for the family's
+// triangles, first and number of the family's members, two unused); the members, two words each (a leaf record's number and the
+// mask of the family's triangles in that leaf); from lists_at on, one record per leaf of the reference's tree (as the flat
+// grid's list records: box min, max, leaf, mask).
 struct ShearHeader {
     float reach;             // a ray enters the sheared tree only if |o| <= reach ...
     float origin_factor;     // ... and o lies outside [hull_min, hull_max] widened by origin_factor * (|o| + radius)
     float radius;            // largest |vertex|
     float hull_min[3], hull_max[3];
-    float pad[7];
+    uint32_t lists_at;       // first word of the leaf records (a multiple of eight)
+    uint32_t members_at;     // first word of the members
+    uint32_t pad[5];
 };
 static_assert(sizeof(ShearHeader) == 64, "ShearHeader is sixteen words");
 constexpr uint32_t kGridListMax = 8;

@@ -591,14 +591,16 @@ private:
         const double pad_uv = radius / 128.0;              // how far outside the two edges at v0 a widened triangle may reach at most
         struct Widened { double corner[3][3]; };
         std::vector<Widened> widened(out_.tris.size());
-        struct Direction { double n[3]; double c; };
+        struct Direction { double n[3]; double c; std::map<uint32_t, uint32_t> members; };   // leaf (its place in leaves_) -> mask of its triangles
         std::vector<Direction> directions;
         double origin_factor = 0.0;
         double hull_lo[3] = {1e300, 1e300, 1e300}, hull_hi[3] = {-1e300, -1e300, -1e300};
-        for (const LeafItem& leaf : leaves_) {
+        for (size_t at = 0; at < leaves_.size(); at++) {
+            const LeafItem& leaf = leaves_[at];
             const uint32_t first = leaf.ref & 0x00FFFFFFu, count = (leaf.ref >> 24) & 0x7Fu;
             for (uint32_t i = first; i < first + count; i++) {
                 if (i >= out_.tris.size()) return;
+                const uint32_t bit = count <= 32 ? (1u << (i - first)) : 0xFFFFFFFFu;     // test_leaf's masks cover leaves of up to 32
                 const TriRec& t = out_.tris[i];
                 const double v0[3] = {t.v0[0], t.v0[1], t.v0[2]}, e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]};
                 const double N[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
@@ -630,11 +632,12 @@ private:
                     const double sgn = along < 0.0 ? -1.0 : 1.0;
                     const double off[3] = {unit_n[0] - sgn * dir.n[0], unit_n[1] - sgn * dir.n[1], unit_n[2] - sgn * dir.n[2]};
                     const double away = std::sqrt(off[0] * off[0] + off[1] * off[1] + off[2] * off[2]);
-                    if (away <= kShearAngle) { dir.c = std::max(dir.c, c + away); found = true; break; }   // |d . n_i| >= |d . n| - |n_i - n|
+                    if (away <= kShearAngle) { dir.c = std::max(dir.c, c + away); dir.members[(uint32_t)at] |= bit; found = true; break; }   // |d . n_i| >= |d . n| - |n_i - n|
                 }
                 if (!found) {
                     if (directions.size() >= kShearMaxDirections) return;
                     Direction dir; dir.n[0] = unit_n[0]; dir.n[1] = unit_n[1]; dir.n[2] = unit_n[2]; dir.c = c;
+                    dir.members[(uint32_t)at] = bit;
                     directions.push_back(dir);
                 }
             }
@@ -692,7 +695,10 @@ private:
         }
         // header, directions, records
         const size_t n_dir = directions.size();
-        const size_t rec_base = ((size_t)16 + 4 * n_dir + 7) & ~(size_t)7;
+        size_t n_members = 0;
+        for (const Direction& dir : directions) n_members += dir.members.size();
+        const size_t members_at = (size_t)16 + 8 * n_dir;
+        const size_t rec_base = (members_at + 2 * n_members + 7) & ~(size_t)7;
         out_.grid.assign(rec_base + 8 * leaves_.size(), 0u);
         ShearHeader header;
         memset(&header, 0, sizeof header);
@@ -700,11 +706,21 @@ private:
         header.origin_factor = round_up(origin_factor * 1.0001);
         header.radius = round_up(radius);
         for (int a = 0; a < 3; a++) { header.hull_min[a] = round_down(hull_lo[a]); header.hull_max[a] = round_up(hull_hi[a]); }
+        header.lists_at = (uint32_t)rec_base;
+        header.members_at = (uint32_t)members_at;
         memcpy(out_.grid.data(), &header, sizeof header);
+        size_t next_member = 0;
         for (size_t k = 0; k < n_dir; k++) {
             const float rec[4] = {(float)directions[k].n[0], (float)directions[k].n[1], (float)directions[k].n[2],
                                   round_up(directions[k].c + 1.0 / 65536.0)};          // the rounding of n and of the dot product
-            memcpy(out_.grid.data() + 16 + 4 * k, rec, 16);
+            uint32_t* at = out_.grid.data() + 16 + 8 * k;
+            memcpy(at, rec, 16);
+            at[4] = (uint32_t)next_member; at[5] = (uint32_t)directions[k].members.size();
+            for (const auto& member : directions[k].members) {
+                out_.grid[members_at + 2 * next_member] = member.first;              // the place in leaves_ is the number of the leaf's record
+                out_.grid[members_at + 2 * next_member + 1] = member.second;
+                next_member++;
+            }
         }
         for (size_t j = 0; j < leaves_.size(); j++) {
             uint32_t* rec = out_.grid.data() + rec_base + 8 * j;

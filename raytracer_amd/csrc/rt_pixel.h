@@ -322,31 +322,47 @@ struct f32x4 { float x, y, z, w; };
 RT_HD f32x4 read_uniform4(const uint32_t* base, uint32_t word) { f32x4 r; memcpy(&r, base + word, 16); return r; }
 #endif
 
-// First record of the leaf lists in MeshArgs::grid (in words): behind the cells of a flat mesh's grid, or behind the header and
-// the directions of a sheared tree.
+// First record of the leaf lists in MeshArgs::grid (in words): behind the cells of a flat mesh's grid, or where the header of a
+// sheared tree says.
 RT_HD size_t list_base(const MeshArgs& M) {
     if (M.grid_axis < 3u) return (((size_t)M.grid_n * (size_t)M.grid_n) + 7) & ~(size_t)7;
-    return ((size_t)16 + 4 * (size_t)M.grid_n + 7) & ~(size_t)7;
+    return (size_t)f32_as_uint(read_uniform4(M.grid, 8).y);
+}
+
+RT_HD int bits_set(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(v);
+#else
+    return __builtin_popcountll(v);
+#endif
+}
+RT_HD int lowest_bit(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((unsigned long long)v) - 1;
+#else
+    return __builtin_ctzll(v);
+#endif
 }
 
 // Whether a ray may walk a mesh's sheared tree (Packer::build_shear states what the tree promises and why these conditions
-// make it hold): origin within reach and outside the widened hull, direction of unit length and at least the stated angle
-// away from the plane of every family of the mesh's triangles.  Every comparison is false for a NaN.
-RT_HD bool shear_gate(const MeshArgs& M, F3 o, F3 d) {
+// make it hold): origin within reach and outside the widened hull, direction of unit length.  `close` gets a bit for every
+// family of the mesh's triangles whose plane the direction comes closer to than the family allows: the tree's boxes say
+// nothing about those triangles for this ray, and the caller tests them apart.  Every comparison is false for a NaN.
+RT_HD bool shear_gate(const MeshArgs& M, F3 o, F3 d, uint64_t& close) {
     const f32x4 h0 = read_uniform4(M.grid, 0), h1 = read_uniform4(M.grid, 4), h2 = read_uniform4(M.grid, 8);
     const float reach = h0.x, origin_factor = h0.y, radius = h0.z;
     const float oo = dot(o, o), dd = dot(d, d);
+    close = 0;
     if (!(oo <= reach * reach) || !(fabsf(dd - 1.0f) <= 0.0009765625f)) return false;
     const float wide = origin_factor * (sqrtf(oo) + radius);
     const bool outside = o.x < h0.w - wide || o.y < h1.x - wide || o.z < h1.y - wide ||
                          o.x > h1.z + wide || o.y > h1.w + wide || o.z > h2.x + wide;
     if (!outside) return false;
-    bool ok = true;
     for (int32_t k = 0; k < M.grid_n; k++) {
-        const f32x4 n = read_uniform4(M.grid, 16u + 4u * (uint32_t)k);
-        ok = ok && fabsf(d.x * n.x + d.y * n.y + d.z * n.z) >= n.w;
+        const f32x4 n = read_uniform4(M.grid, 16u + 8u * (uint32_t)k);
+        if (!(fabsf(d.x * n.x + d.y * n.y + d.z * n.z) >= n.w)) close |= (uint64_t)1 << k;
     }
-    return ok;
+    return true;
 }
 
 // Where a ray starts its walk in a flat mesh (MeshArgs::grid, built by Packer::build_grid): the node stored for the cell
@@ -400,40 +416,58 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
                 if (!(plane_t > 0.0f) || (CULL && plane_t > q.limit)) return false;
             }
         }
-        else if (use_grid && M.grid_axis >= 4u && ref == M.root_ref && shear_gate(M, o, d)) {
+        uint64_t apart = 0;                  // families of triangles that a walk through the sheared tree has to test apart
+        if (use_grid && M.grid_axis >= 4u && ref == M.root_ref) {
             // the tree in the sheared frame: same records, same slab arithmetic, on the sheared ray (same t); its leaves are
             // lists of one record, whose own box test is the reference's for that leaf
+            uint64_t close;
             const F3 sd = shear(d, M.grid_axis - 4u);
-            if (sd.x != 0.0f && sd.y != 0.0f && sd.z != 0.0f) {
+            if (shear_gate(M, o, d, close) && bits_set(close) <= 3 && sd.x != 0.0f && sd.y != 0.0f && sd.z != 0.0f) {
                 sr = slab_ray(shear(o, M.grid_axis - 4u), recip(sd));
                 ref = M.shear_root;
+                apart = close;
             }
         }
+        const size_t lists_at = M.grid_axis != 3u ? list_base(M) : 0;
         // A list of leaves (a flat mesh's cell, a leaf of a sheared tree): each one's own box test (the reference reaches a leaf
         // exactly when that passes, the boxes above contain it), then its triangles.  True when an any-hit query may stop.
-        auto run_list = [&](const uint32_t list) -> bool {
-            const uint32_t count = (list >> 24) & 0xFu;
-            const size_t first = list_base(M) + (size_t)(list & 0x00FFFFFFu) * 8;
-            for (uint32_t i = 0; i < count; i++) {
+        // `only`: the triangles of the leaf to look at (a mask like the record's own)
+        auto run_record = [&](const size_t at, const uint32_t only) -> bool {
+            {
                 float bmin[3], bmax[3];
-                const size_t at = first + (size_t)i * 8;
 #if defined(__HIP_DEVICE_COMPILE__)
                 const f32x4 r0 = global_read<f32x4>(M.grid, at * 4), r1 = global_read<f32x4>(M.grid, at * 4 + 16);     // records are 32-byte aligned
                 bmin[0] = r0.x; bmin[1] = r0.y; bmin[2] = r0.z; bmax[0] = r0.w; bmax[1] = r1.x; bmax[2] = r1.y;
-                const uint32_t leaf = f32_as_uint(r1.z), mask = f32_as_uint(r1.w);
+                const uint32_t leaf = f32_as_uint(r1.z), mask = f32_as_uint(r1.w) & only;
 #else
                 RT_UNROLL
                 for (int c = 0; c < 3; c++) { bmin[c] = uint_as_f32(read_word(M.grid, at + c)); bmax[c] = uint_as_f32(read_word(M.grid, at + 3 + c)); }
-                const uint32_t leaf = read_word(M.grid, at + 6), mask = read_word(M.grid, at + 7);
+                const uint32_t leaf = read_word(M.grid, at + 6), mask = read_word(M.grid, at + 7) & only;
 #endif
                 if (COUNT) work.slabs++;
                 float entry;
-                if (!slab_t(o, inv, bmin, bmax, entry)) continue;
-                if (CULL && entry > q.limit) continue;
-                if (test_leaf<ANY, COUNT, FULL, LB>(M, nodes, leaf, o, d, q, work, mask)) return true;
+                if (!slab_t(o, inv, bmin, bmax, entry)) return false;
+                if (CULL && entry > q.limit) return false;
+                return test_leaf<ANY, COUNT, FULL, LB>(M, nodes, leaf, o, d, q, work, mask);
             }
+        };
+        auto run_list = [&](const uint32_t list) -> bool {
+            const uint32_t count = (list >> 24) & 0xFu;
+            const size_t first = lists_at + (size_t)(list & 0x00FFFFFFu) * 8;
+            for (uint32_t i = 0; i < count; i++)
+                if (run_record(first + (size_t)i * 8, 0xFFFFFFFFu)) return true;
             return false;
         };
+        // the families the sheared tree cannot speak for: every leaf that holds one of their triangles, those triangles only
+        while (apart) {
+            const int k = lowest_bit(apart);
+            apart &= apart - 1;
+            const uint32_t first = read_word(M.grid, 16 + 8 * (size_t)k + 4), count = read_word(M.grid, 16 + 8 * (size_t)k + 5);
+            for (uint32_t i = 0; i < count; i++) {
+                const size_t member = (size_t)f32_as_uint(read_uniform4(M.grid, 8).z) + 2 * (size_t)(first + i);
+                if (run_record(lists_at + (size_t)read_word(M.grid, member) * 8, read_word(M.grid, member + 1))) return true;
+            }
+        }
         if (!(ref & kLeafBit) && (ref & kGridListBit)) {             // the cell of a flat mesh's grid names its leaves: nothing else to do
             if (run_list(ref)) return true;
             hit = q.hit;

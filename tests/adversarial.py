@@ -118,6 +118,67 @@ def scenes(po, seed=0):
     yield "zero and NaN normals, texture coordinates far outside the unit square", [rows], [ident], default_cam, 160, 90
 
 
+def _beam(a, b, width, up):
+    """A box of twelve triangles around the segment a-b: `width` wide across the segment in the plane normal to `up`, and
+    as tall along `up`."""
+    a, b, up = np.asarray(a, float), np.asarray(b, float), np.asarray(up, float)
+    along = (b - a) / np.linalg.norm(b - a)
+    side = np.cross(up, along)
+    side *= 0.5 * width / np.linalg.norm(side)
+    rise = up * (0.5 * width / np.linalg.norm(up))
+    c = [p + sx * side + sy * rise for p in (a, b) for sx in (-1, 1) for sy in (-1, 1)]      # index = 4 end + 2 side + rise
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    rows = []
+    for q in quads:
+        rows.append(_tri(c[q[0]], c[q[1]], c[q[2]]))
+        rows.append(_tri(c[q[0]], c[q[2]], c[q[3]]))
+    return rows
+
+
+def diagonal_frames(po, seed=0):
+    """Meshes of long thin beams along the diagonals of a coordinate plane -- what the packer gives a tree in a sheared frame
+    (Packer::build_shear) -- seen from where that tree's conditions hold and from where they do not: a general view, views
+    whose rays run inside the planes of the beams' faces (those faces' triangles are tested apart), a camera inside the
+    hull of the widened triangles and one touching a beam (the other trees), one beyond the tree's reach, views along the
+    axes.  Yields (name, soups, transforms, camera, light, width, height, kept axis of the expected frame)."""
+    rng = np.random.default_rng(seed)
+    light = po.default_light()
+    axes = np.eye(3)
+    for kept in (1, 0, 2):
+        up = axes[kept]
+        a, b = axes[(kept + 1) % 3], axes[(kept + 2) % 3]
+        rows = []
+        for off in np.linspace(-0.6, 0.6, 7):
+            rows += _beam(-(a + b) + off * (a - b) * 0.5, (a + b) + off * (a - b) * 0.5, 0.03, up)
+            rows += _beam(-(a - b) + off * (a + b) * 0.5, (a - b) + off * (a + b) * 0.5, 0.02, up)
+        rows += _blob(rng, up * 0.2, 0.15, 40, size=0.2)                    # a hub of small triangles facing every way
+        ident = po.Transform(po.vec3(0, 0, 0), po.vec3(0, 0, 0))
+        turned = po.Transform(po.vec3(0.3, 0.2, -0.1), po.vec3(0.2, 0.7, -0.4))
+        floor = [_tri(-3 * (a + b) - 1.5 * up, 3 * (a - b) - 1.5 * up, 3 * (a + b) - 1.5 * up),
+                 _tri(-3 * (a + b) - 1.5 * up, 3 * (a + b) - 1.5 * up, -3 * (a - b) - 1.5 * up)]
+        soups = [rows, floor]
+
+        def cam(pos, at=(0, 0, 0), fov=50.0):
+            u = up if abs(np.dot(np.subtract(at, pos), up)) < 0.99 * np.linalg.norm(np.subtract(at, pos)) else a
+            return po.Camera(po.vec3(*pos), po.vec3(*at), po.vec3(*u), fov)
+        views = [("general view", ident, cam(2.0 * up + 1.3 * a + 0.4 * b)),
+                 ("placed and turned", turned, cam(2.5 * up - 1.0 * a + 2.0 * b)),
+                 ("view inside the planes of one diagonal's faces", ident, cam(1.5 * up + 1.5 * (a + b), fov=30.0)),
+                 ("view inside the planes of the other diagonal's faces", ident, cam(1.0 * up + 2.0 * (a - b), fov=30.0)),
+                 ("view along the beams' tops", ident, cam(0.015 * up + 3.0 * a, at=0.015 * up, fov=40.0)),
+                 ("camera between the beams", ident, cam(0.05 * up + 0.1 * a, at=2.0 * a + 1.0 * b)),
+                 ("camera on a beam's face", ident, cam(0.0151 * up + 0.3 * (a + b), at=0.5 * up + a)),
+                 ("camera just above the beams", ident, cam(0.3 * up, at=a + 0.2 * b, fov=90.0)),
+                 ("camera beyond the tree's reach", ident, cam(9.0 * up + 6.0 * a + 2.0 * b, fov=15.0)),
+                 ("view along the kept axis", ident, cam(3.0 * up, fov=40.0)),
+                 ("view along a sheared axis", ident, cam(3.0 * a, fov=40.0))]
+        for name, tf, c in views:
+            yield f"beams in the plane normal to axis {kept}: {name}", soups, [tf, ident], c, light, 128, 80, kept
+        for ldir in ((1, 1, 1), tuple(a + b + 0.001 * up), tuple(up), tuple(0.7 * up + a - b)):
+            l = po.lib().orc_make_light(po.vec3(*ldir), po.vec3(1.0, 0.9, 0.8))
+            yield f"beams in the plane normal to axis {kept}: light {ldir}", soups, [turned, ident], cam(2.0 * up + 1.3 * a + 0.4 * b), l, 128, 80, kept
+
+
 def build(po, soups, texture):
     """Oracle-side meshes (reference build of every soup)."""
     out = []

@@ -78,6 +78,8 @@ def lib():
         L.emul_work_plane.argtypes = [vp, vp]
         L.emul_work_plane.restype = None
         L.emul_mesh_wide.argtypes = [vp, i32]
+        L.emul_mesh_grid_axis.argtypes = [vp, i32]
+        L.emul_damage_shear.argtypes = [vp, i32]
         L.emul_set_loose.argtypes = [vp, i32]
         L.emul_set_loose.restype = None
         L.emul_set_vis_shrink.argtypes = [vp, i32]
@@ -217,6 +219,15 @@ class Scene:
         r = lib().emul_mesh_wide(self.h, int(mesh))
         assert r >= 0
         return bool(r)
+
+    def grid_axis(self, mesh: int) -> int:
+        """0..2: flat mesh with a grid; 3: neither; 4 + k: a tree in the sheared frame that keeps axis k."""
+        r = lib().emul_mesh_grid_axis(self.h, int(mesh))
+        assert r >= 0
+        return r
+
+    def damage_shear(self, mesh: int) -> int:
+        return lib().emul_damage_shear(self.h, int(mesh))
 
     def set_loose(self, on: bool):
         """Rays enter every mesh through its tree of single triangles (what the kernels' fast build walks); not bit-exact."""

@@ -149,6 +149,24 @@ int emul_mesh_wide(void* sp, int mesh) {
     if (mesh < 0 || mesh >= (int)s->meshes.size()) return -1;
     return s->meshes[(size_t)mesh].pk.wide ? 1 : 0;
 }
+// MeshArgs::grid_axis of the mesh: 0..2 a flat mesh's grid, 3 nothing, 4 + k a tree in the sheared frame that keeps axis k.
+int emul_mesh_grid_axis(void* sp, int mesh) {
+    EmulScene* s = (EmulScene*)sp;
+    if (mesh < 0 || mesh >= (int)s->meshes.size()) return -1;
+    return (int)s->meshes[(size_t)mesh].pk.grid_axis;
+}
+// Deliberate damage: every box of the sheared tree's root moved out of every ray's way.
+int emul_damage_shear(void* sp, int mesh) {
+    EmulScene* s = (EmulScene*)sp;
+    if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;
+    const PackedMesh& pk = s->meshes[(size_t)mesh].pk;
+    if (pk.grid_axis < 4 || (pk.shear_root & (kLeafBit | kGridListBit))) return RT_ERR_UNSUPPORTED;
+    size_t base = 0;
+    for (int m = 0; m < mesh; m++) base += s->meshes[(size_t)m].pk.pairs.size();
+    PairNode& root = s->all_pairs[base + pk.shear_root];
+    for (int a = 0; a < 3; a++) { root.lmin[a] = 1.0e30f; root.lmax[a] = 1.1e30f; }
+    return RT_OK;
+}
 int emul_mesh_info(void* sp, int mesh, int32_t* n_pairs, int32_t* depth, uint32_t* root_ref) {
     EmulScene* s = (EmulScene*)sp;
     if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;

@@ -180,6 +180,34 @@ def test_damaged_shortcuts_are_noticed(po, meshes):
     c = s.render(cam, light, tfs, 240, 135, verify=True)["counters"]
     assert c["entry_disagreements"] > 1000 and c["cull_disagreements"] == 0 and c["vis_disagreements"] == 0, c
     s.close()
+    s = emul.Scene(regroup=True)
+    for m in meshes:
+        assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+    assert s.grid_axis(0) == 5 and s.damage_shear(0) == 0      # the drone's tree in the sheared frame has lost half of itself
+    c = s.render(cam, light, tfs, 240, 135, verify=True)["counters"]
+    assert c["entry_disagreements"] > 100 and c["cull_disagreements"] == 0 and c["vis_disagreements"] == 0, c
+    s.close()
+
+
+def test_meshes_of_diagonal_beams_check_their_sheared_tree(po):
+    """tests/adversarial.py::diagonal_frames: the packer gives those meshes a tree in the sheared frame of their plane; from
+    every view -- rays the tree may take, rays that test some families of triangles apart, rays that have to take the other
+    trees -- the frame is the oracle's and the walk through that tree ends like the walk from the root."""
+    import adversarial
+    tex = checker()
+    n = 0
+    for name, soups, tfs, cam, light, w, h, kept in adversarial.diagonal_frames(po):
+        hm = adversarial.build(po, soups, tex)
+        s = emul.Scene(regroup=True)
+        for m in hm:
+            assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+        assert s.grid_axis(0) == 4 + kept and s.grid_axis(1) < 4, name
+        got = s.render(cam, light, tfs, w, h, verify=True)
+        assert_planes(got, po.render_frame(hm, tfs, cam, light, w, h), name)
+        assert_clean(got["counters"], name)
+        s.close()
+        n += 1
+    assert n >= 40
 
 
 # ------------------------------------------------------------------------------------------ GPU: through the C ABI
@@ -255,6 +283,34 @@ def test_gpu_scenes_aimed_at_the_margins_check_themselves(capi, po):
         assert_clean(got["counters"], name)
         n += 1
     assert n >= 20
+
+
+@pytest.mark.gpu
+def test_gpu_meshes_of_diagonal_beams_check_their_sheared_tree(capi, po):
+    """The same scenes through the C ABI: the self-checking frame, the plain frame with all planes and the batched frames."""
+    import torch
+    import adversarial
+    tex = checker()
+    n = 0
+    for name, soups, tfs, cam, light, w, h, kept in adversarial.diagonal_frames(po):
+        hm = adversarial.build(po, soups, tex)
+        want = po.render_frame(hm, tfs, cam, light, w, h)
+        cl = clight(capi, light)
+        with capi.Context(0) as c:
+            for m in hm:
+                c.upload_mesh(m.tris, m.nodes, m.rgba)
+            got = gpu_checked(capi, c, cam, light, tfs, w, h)
+            assert_planes(got, want, name)
+            assert_clean(got["counters"], name)
+            rgb, hid, ht, sh = c.render_host(ccam(capi, cam), cl, conv(capi, tfs), w, h)
+            assert np.array_equal(rgb, want.rgb) and np.array_equal(hid, want.hit_id) and np.array_equal(sh, want.shadow), name
+            assert np.array_equal(ht.view(np.uint32), want.hit_t.view(np.uint32)), name
+            out = torch.zeros((2, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            c.render_frames(ccam(capi, cam), cl, [conv(capi, tfs)] * 2, w, h, out)
+            c.sync()
+            assert np.array_equal(out[0].cpu().numpy(), want.rgb) and np.array_equal(out[1].cpu().numpy(), want.rgb), name
+        n += 1
+    assert n >= 40
 
 
 @pytest.mark.gpu
