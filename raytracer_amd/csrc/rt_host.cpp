@@ -36,7 +36,8 @@ struct DeviceMesh {
     TriRec* d_tris = nullptr;
     AttrRec* d_attrs = nullptr;
     uint32_t* d_texels = nullptr;
-    uint32_t* d_grid = nullptr;    // flat meshes: entry references per cell (Packer::build_grid)
+    uint32_t* d_grid = nullptr;    // flat meshes: entry references per cell (Packer::build_grid); sheared tree: its header, families and records
+    std::vector<uint32_t> shear_blob;   // host copy of the latter, for the per-frame part of its gate (shear_frame_masks)
     MeshArgs proto;          // static part filled at upload; placement filled per frame
     int32_t n_tris = 0, n_pairs = 0;
     // the tree over the triangles themselves that the fast build walks (Packer::build_loose) and its own copy of the triangle
@@ -208,6 +209,8 @@ int set_geometry(rt_ctx* ctx, DeviceMesh& dm, const PackedMesh& pk, int32_t n_tr
         if (gst != RT_OK) return gst;
     }
     set_grid_args(pk, dm.d_grid, dm.proto);
+    dm.shear_blob.clear();
+    if (pk.grid_axis >= 4) dm.shear_blob = pk.grid;
     dm.pairs = pk.pairs; dm.tris = pk.tris; dm.depth = pk.depth; dm.host_tris = true;
     dm.proto.tris = dm.d_tris; dm.proto.attrs = dm.d_attrs;
     memcpy(dm.proto.root_min, pk.root_min, 12);
@@ -393,6 +396,7 @@ void fill_frame(const rt_ctx* ctx, const rt_camera& camera, const rt_light& ligh
         A.mesh[m] = ctx->meshes[(size_t)m].proto;
         if (fast_kernels) enter_loose_tree(ctx->meshes[(size_t)m], A.mesh[m]);
         fill_placement(transforms[m], A, A.mesh[m]);
+        if (A.mesh[m].grid_axis >= 4u) shear_frame_masks(ctx->meshes[(size_t)m].shear_blob.data(), A.mesh[m]);
         if (ctx->screen_cull) mesh_screen_rect(transforms[m], A.mesh[m].root_min, A.mesh[m].root_max, A, A.vis[m]);
         else { A.vis[m][0] = 0; A.vis[m][1] = 0; A.vis[m][2] = (width + 7) / 8; A.vis[m][3] = (height + 7) / 8; }
         for (int i = 0; i < 4; i++) A.vis_shadow[m][i] = i < 2 ? 0 : (i == 2 ? (width + 7) / 8 : (height + 7) / 8);

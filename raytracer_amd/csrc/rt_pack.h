@@ -159,6 +159,54 @@ struct PackedMesh {
     uint32_t shear_pairs = 0;
 };
 
+// Per-frame part of a sheared tree's gate (rt_pixel.h: shear_gate), for a MeshArgs whose placement constants are filled in;
+// `blob` is the host copy of what MeshArgs::grid points to.  Which families of the mesh's triangles a ray runs too close to is
+// a question about its direction alone.  Every shadow ray of the frame has the direction lit_d: the answer is given here, once
+// (grid_inv: the mask of close families).  The camera rays that reach the gate pass the mesh's root box, so their directions
+// lie in the cone from cam_o around that box: families whose plane stays clear of the whole cone need no test per ray (grid_lo:
+// the mask of families still to test).  grid_slack[0] says which of the two is valid (bit 0 camera, bit 1 shadow).  Both err
+// on the side of testing: a family is left out only where double arithmetic clears it with room to spare.
+inline void shear_frame_masks(const uint32_t* blob, MeshArgs& M) {
+    if (M.grid_axis < 4u || !blob) return;
+    const int n = M.grid_n;
+    uint64_t shadow_close = 0, camera_check = 0;
+    bool shadow_ok = true, camera_ok = true;
+    double d[3] = {M.lit_d[0], M.lit_d[1], M.lit_d[2]};
+    // the cone of the camera rays: from cam_o around the sphere that holds the root box (a tenth larger: a ray that passes the
+    // float slab test passes the box itself to within rounding)
+    double centre[3], half = 0.0, to[3], dist = 0.0;
+    for (int a = 0; a < 3; a++) {
+        centre[a] = 0.5 * ((double)M.root_min[a] + (double)M.root_max[a]);
+        const double h = 0.5 * ((double)M.root_max[a] - (double)M.root_min[a]);
+        half += h * h;
+        to[a] = centre[a] - (double)M.cam_o[a];
+        dist += to[a] * to[a];
+    }
+    half = std::sqrt(half) * 1.1 + 1e-3;
+    dist = std::sqrt(dist);
+    if (!(dist > 1.5 * half) || !(dist < 1e15)) camera_ok = false;
+    const double sin_cone = camera_ok ? half / dist : 1.0, cos_cone = std::sqrt(1.0 - sin_cone * sin_cone);
+    for (int k = 0; k < n && k < 64; k++) {
+        float rec[4];
+        memcpy(rec, blob + 16 + 8 * (size_t)k, 16);
+        const double c = rec[3];
+        const double along = std::fabs(d[0] * rec[0] + d[1] * rec[1] + d[2] * rec[2]);
+        if (!(along >= c + 4e-6)) shadow_close |= (uint64_t)1 << k;          // also when a NaN is about
+        if (camera_ok) {
+            const double axis = std::fabs((to[0] * rec[0] + to[1] * rec[1] + to[2] * rec[2]) / dist);
+            const double across = std::sqrt(std::max(0.0, 1.0 - axis * axis));
+            const double least = axis * cos_cone - across * sin_cone;                    // smallest |d . n| over unit directions in the cone
+            if (!(least * 0.998 >= c + 1e-5)) camera_check |= (uint64_t)1 << k;           // 0.998: the gate admits |d| within a thousandth of 1
+        }
+    }
+    if (n > 64) shadow_ok = camera_ok = false;
+    uint32_t w[4] = {(uint32_t)camera_check, (uint32_t)(camera_check >> 32), (uint32_t)shadow_close, (uint32_t)(shadow_close >> 32)};
+    memcpy(&M.grid_lo[0], &w[0], 4); memcpy(&M.grid_lo[1], &w[1], 4);
+    memcpy(&M.grid_inv[0], &w[2], 4); memcpy(&M.grid_inv[1], &w[3], 4);
+    const uint32_t valid = (camera_ok ? 1u : 0u) | (shadow_ok ? 2u : 0u);
+    memcpy(&M.grid_slack[0], &valid, 4);
+}
+
 // The grid fields of a MeshArgs from a packed mesh; d_grid = where pk.grid lives for the code that will traverse.
 inline void set_grid_args(const PackedMesh& pk, const uint32_t* d_grid, MeshArgs& M) {
     M.grid = pk.grid_axis != 3 ? d_grid : nullptr;

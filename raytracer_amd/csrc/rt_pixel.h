@@ -348,6 +348,9 @@ RT_HD int lowest_bit(uint64_t v) {
 // make it hold): origin within reach and outside the widened hull, direction of unit length.  `close` gets a bit for every
 // family of the mesh's triangles whose plane the direction comes closer to than the family allows: the tree's boxes say
 // nothing about those triangles for this ray, and the caller tests them apart.  Every comparison is false for a NaN.
+// Per frame the host has answered part of the question (shear_frame_masks in rt_pack.h): for the shadow rays' common direction
+// MeshArgs::lit_d it names the close families outright, and for rays from MeshArgs::cam_o it names the families that any ray
+// through the root box can come close to at all -- the others are not looked at.
 RT_HD bool shear_gate(const MeshArgs& M, F3 o, F3 d, uint64_t& close) {
     const f32x4 h0 = read_uniform4(M.grid, 0), h1 = read_uniform4(M.grid, 4), h2 = read_uniform4(M.grid, 8);
     const float reach = h0.x, origin_factor = h0.y, radius = h0.z;
@@ -358,7 +361,19 @@ RT_HD bool shear_gate(const MeshArgs& M, F3 o, F3 d, uint64_t& close) {
     const bool outside = o.x < h0.w - wide || o.y < h1.x - wide || o.z < h1.y - wide ||
                          o.x > h1.z + wide || o.y > h1.w + wide || o.z > h2.x + wide;
     if (!outside) return false;
-    for (int32_t k = 0; k < M.grid_n; k++) {
+    const uint32_t valid = f32_as_uint(M.grid_slack[0]);
+    if ((valid & 2u) && f32_as_uint(d.x) == f32_as_uint(M.lit_d[0]) && f32_as_uint(d.y) == f32_as_uint(M.lit_d[1]) &&
+        f32_as_uint(d.z) == f32_as_uint(M.lit_d[2])) {
+        close = (uint64_t)f32_as_uint(M.grid_inv[0]) | ((uint64_t)f32_as_uint(M.grid_inv[1]) << 32);
+        return true;
+    }
+    uint64_t check = M.grid_n >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << M.grid_n) - 1);
+    if ((valid & 1u) && f32_as_uint(o.x) == f32_as_uint(M.cam_o[0]) && f32_as_uint(o.y) == f32_as_uint(M.cam_o[1]) &&
+        f32_as_uint(o.z) == f32_as_uint(M.cam_o[2]))
+        check = (uint64_t)f32_as_uint(M.grid_lo[0]) | ((uint64_t)f32_as_uint(M.grid_lo[1]) << 32);
+    while (check) {
+        const int k = lowest_bit(check);
+        check &= check - 1;
         const f32x4 n = read_uniform4(M.grid, 16u + 8u * (uint32_t)k);
         if (!(fabsf(d.x * n.x + d.y * n.y + d.z * n.z) >= n.w)) close |= (uint64_t)1 << k;
     }

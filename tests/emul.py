@@ -226,6 +226,17 @@ class Scene:
         assert r >= 0
         return r
 
+    def shear_masks_hold(self, mesh, cam, light, tf, w, h):
+        """(rays for which the host's per-frame masks miss a family the gate itself finds close, rays compared, families spared)."""
+        looked, spared = C.c_longlong(0), C.c_longlong(0)
+        cam2, light2, tf2 = conv(cam, Camera), conv(light, Light), conv(tf, Transform)
+        L = lib()
+        L.emul_shear_masks_hold.restype = C.c_longlong
+        L.emul_shear_masks_hold.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Camera), C.POINTER(Light), C.POINTER(Transform), C.c_int32, C.c_int32,
+                                            C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        bad = L.emul_shear_masks_hold(self.h, int(mesh), C.byref(cam2), C.byref(light2), C.byref(tf2), int(w), int(h), C.byref(looked), C.byref(spared))
+        return int(bad), looked.value, spared.value
+
     def damage_shear(self, mesh: int) -> int:
         return lib().emul_damage_shear(self.h, int(mesh))
 

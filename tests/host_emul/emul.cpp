@@ -167,6 +167,54 @@ int emul_damage_shear(void* sp, int mesh) {
     for (int a = 0; a < 3; a++) { root.lmin[a] = 1.0e30f; root.lmax[a] = 1.1e30f; }
     return RT_OK;
 }
+// The per-frame part of a sheared tree's gate against the gate itself: for every camera ray of the frame that passes the mesh's
+// root box, and for the frame's shadow direction, the families the gate finds close when it looks at all of them must be among
+// those it finds with the host's masks.  Returns the number of rays for which they are not (-1: the mesh has no such tree);
+// *looked gets the number of rays compared, *spared the families the masks let the camera rays skip, summed over those rays.
+long long emul_shear_masks_hold(void* sp, int mesh, const rt_camera* cam, const rt_light* light, const rt_transform* tf, int32_t width, int32_t height,
+                                long long* looked, long long* spared) {
+    EmulScene* s = (EmulScene*)sp;
+    if (mesh < 0 || mesh >= (int)s->meshes.size()) return -1;
+    const EmulMesh& E = s->meshes[(size_t)mesh];
+    if (E.pk.grid_axis < 4) return -1;
+    FrameArgs A; memset(&A, 0, sizeof A);
+    fill_camera(*cam, *light, width, height, A);
+    MeshArgs M; memset(&M, 0, sizeof M);
+    memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
+    set_grid_args(E.pk, E.pk.grid.data(), M);
+    fill_placement(*tf, A, M);
+    MeshArgs plain = M;
+    shear_frame_masks(E.pk.grid.data(), M);
+    long long bad = 0, n = 0, skipped = 0;
+    const uint64_t all = M.grid_n >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << M.grid_n) - 1);
+    uint32_t valid; memcpy(&valid, &M.grid_slack[0], 4);
+    uint32_t w0, w1; memcpy(&w0, &M.grid_lo[0], 4); memcpy(&w1, &M.grid_lo[1], 4);
+    const uint64_t check = (valid & 1u) ? ((uint64_t)w0 | ((uint64_t)w1 << 32)) : all;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const float fx = ((float)x + 0.5f) / (float)A.width, fy = ((float)y + 0.5f) / (float)A.full_height;
+            const float rx = (2.0f * fx - 1.0f) * A.aspect * A.scale, ry = (1.0f - 2.0f * fy) * A.scale;
+            const F3 wd = unit(add(add(scale(f3(A.cam_right), rx), scale(f3(A.cam_up), ry)), f3(A.cam_fwd)));
+            const F3 ld = unit(xform_vector<4>(M.inv, wd));
+            float entry;
+            if (!slab_t(f3(M.cam_o), recip(ld), M.root_min, M.root_max, entry)) continue;
+            uint64_t full = 0, masked = 0;
+            const bool a = shear_gate(plain, f3(M.cam_o), ld, full), b = shear_gate(M, f3(M.cam_o), ld, masked);
+            if (a != b) { bad++; continue; }
+            if (!a) continue;
+            n++;
+            skipped += bits_set(all & ~check);
+            if (full & ~masked) bad++;
+        }
+    // the shadow direction, from an origin the gate admits
+    const F3 o = f3(M.cam_o);
+    uint64_t full = 0, masked = 0;
+    const bool a = shear_gate(plain, o, f3(M.lit_d), full), b = shear_gate(M, o, f3(M.lit_d), masked);
+    if (a != b || (a && (full & ~masked))) bad++;
+    if (a) n++;
+    *looked = n; *spared = skipped;
+    return bad;
+}
 int emul_mesh_info(void* sp, int mesh, int32_t* n_pairs, int32_t* depth, uint32_t* root_ref) {
     EmulScene* s = (EmulScene*)sp;
     if (mesh < 0 || mesh >= (int)s->meshes.size()) return RT_ERR_INVALID;
@@ -233,6 +281,7 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u; M.wide = E.pk.wide ? 1u : 0u;
         if (s->loose && M.grid_axis >= 4u) { M.grid_axis = 3u; M.grid = nullptr; }
         fill_placement(tfs[m], A, M);
+        shear_frame_masks(E.pk.grid.data(), M);
         mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
     }
     {   // shadow-ray rectangles, as the product's fill_frame computes them
@@ -312,6 +361,7 @@ int emul_render_sampled(void* sp, const rt_camera* cam, const rt_light* lights, 
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
         M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root; set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u; M.wide = E.pk.wide ? 1u : 0u;
         fill_placement(tfs[m], A, M);
+        shear_frame_masks(E.pk.grid.data(), M);
         mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
     }
     SampleArgs X;

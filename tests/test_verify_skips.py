@@ -285,6 +285,33 @@ def test_gpu_scenes_aimed_at_the_margins_check_themselves(capi, po):
     assert n >= 20
 
 
+def test_per_frame_masks_of_the_sheared_tree_never_hide_a_close_family(po, meshes):
+    """Which families of the drone's triangles a ray runs too close to is decided per ray (shear_gate); per frame the host
+    answers it for the shadow rays' direction and rules families out for all camera rays through the root box
+    (shear_frame_masks).  Over the animation and 300 random placements, cameras and lights: whatever the gate flags when it
+    looks at every family, it flags with the masks too -- and the masks do spare it work."""
+    s = emul.Scene(regroup=True)
+    for m in meshes:
+        assert s.add(m.tris, m.nodes, m.rgba) == 0, s.error()
+    assert s.grid_axis(0) == 5
+    looked = spared = 0
+    for frame in (0, 24, 48, 72, 95):
+        bad, n, k = s.shear_masks_hold(0, po.default_camera(), po.default_light(), po.animation_transforms(frame)[0], 480, 270)
+        assert bad == 0, frame
+        looked += n; spared += k
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        tf = po.Transform(po.vec3(*rng.uniform(-2, 2, 3)), po.vec3(*rng.uniform(-3.2, 3.2, 3)))
+        cam = po.Camera(po.vec3(*rng.uniform(-5, 5, 3)), po.vec3(*(np.array(tf.position.tup()) + rng.normal(0, 0.5, 3))), po.vec3(0, 1, 0),
+                        float(rng.uniform(20, 100)))
+        light = po.lib().orc_make_light(po.vec3(*rng.uniform(-1, 1, 3)), po.vec3(1, 1, 1))
+        bad, n, k = s.shear_masks_hold(0, cam, light, tf, 96, 54)
+        assert bad == 0
+        looked += n; spared += k
+    assert looked > 100000 and spared > 10 * looked
+    s.close()
+
+
 @pytest.mark.gpu
 def test_gpu_meshes_of_diagonal_beams_check_their_sheared_tree(capi, po):
     """The same scenes through the C ABI: the self-checking frame, the plain frame with all planes and the batched frames."""
