@@ -323,10 +323,15 @@ def main():
     say("work counted")
 
     # ---- warm-up
+    # launches of equal size (to within one frame), none larger than a.batch: 20 steps are two launches of 10, not 16 + 4 --
+    # a launch's last tiles keep the whole GPU waiting, and they weigh most in a small launch
     nb = (a.steps + a.batch - 1) // a.batch
-    batches = [seq[b * a.batch:min((b + 1) * a.batch, a.steps)] for b in range(nb)]
+    per = (a.steps + nb - 1) // nb
+    sizes = [per if b < a.steps - nb * (per - 1) else per - 1 for b in range(nb)]
+    bounds = [sum(sizes[:b]) for b in range(nb + 1)]
+    batches = [seq[bounds[b]:bounds[b + 1]] for b in range(nb)]
     RING = 4                                                   # batches in flight: send buffers and gathers
-    bufs = [torch.empty((a.batch, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(min(nb, RING))]
+    bufs = [torch.empty((per, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(min(nb, RING))]
     for buf in bufs:                                           # first touch of every output buffer happens here, untimed
         buf.zero_()                                            # (on the current stream = the render stream)
     # The timed region of the default run lasts some 15 ms, less than the GPU needs to reach its working clocks
@@ -335,8 +340,8 @@ def main():
     if not rehearse:
         for k in range(SETTLE):                                 # the launches of the timed region, in turn
             scene.render_frames(batches[k % nb], W, H, bufs[k % len(bufs)], stream=sptr)
-    for k, i in enumerate(range(0, a.warmup, a.batch)):
-        scene.render_frames(warm[i:min(i + a.batch, a.warmup)], W, H, bufs[k % len(bufs)], stream=sptr)
+    for k, i in enumerate(range(0, a.warmup, per)):
+        scene.render_frames(warm[i:min(i + per, a.warmup)], W, H, bufs[k % len(bufs)], stream=sptr)
     if grouped:
         g = sharding.FrameGather(rank, world, collective_at_one_rank=grouped)
         g.submit(bufs[0])
@@ -355,7 +360,7 @@ def main():
         b = seq_no % nb
         for r, t in enumerate(per_rank):
             sh = sharding.frames_for_rank(NF, r, world) or [r % NF]
-            theirs = frame_sequence(sh, a.steps)[b * a.batch:min((b + 1) * a.batch, a.steps)]
+            theirs = frame_sequence(sh, a.steps)[bounds[b]:bounds[b + 1]]
             for k, f in enumerate(theirs):
                 verified[0] += 1
                 verified[1] += int(bool((t[k] == (37 * f + 11) % 251).all()))
@@ -418,7 +423,7 @@ def main():
     if grouped:
         def first_batch(r):
             sh = sharding.frames_for_rank(NF, r, world) or [r % NF]
-            fr = frame_sequence(sh, a.batch)
+            fr = frame_sequence(sh, per)
             return fr
         scene.render_frames(first_batch(rank), W, H, bufs[0], stream=sptr)
         g = sharding.FrameGather(rank, world, collective_at_one_rank=grouped)
@@ -451,7 +456,7 @@ def main():
             alg_bytes.append(sum(work(info[f])[0] for f in fr)); alg_flops.append(sum(work(info[f])[1] for f in fr))
             own_bytes.append(sum(work(own[f])[0] for f in fr)); own_flops.append(sum(work(own[f])[1] for f in fr))
         # full-size launches only (the last launch of the region may hold fewer frames)
-        full = [i for i, fr in enumerate(batches) if len(fr) == a.batch] or list(range(len(batches)))
+        full = [i for i, fr in enumerate(batches) if len(fr) == per] or list(range(len(batches)))
         ms, alg_bytes, alg_flops = [ms[i] for i in full], [alg_bytes[i] for i in full], [alg_flops[i] for i in full]
         own_bytes, own_flops = [own_bytes[i] for i in full], [own_flops[i] for i in full]
         launch_frames = float(np.mean([len(batches[i]) for i in full]))
@@ -460,7 +465,7 @@ def main():
         tfl = float(np.mean(alg_flops)) / secs / 1e12
         roof = {"bound": "valu", "achieved": round(tfl, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tfl / VALU_PEAK_TFLOPS, 5), "traffic": None, "hbm_frac": None,
-                "kernel": "render_batch (block %d), %d frames per launch (the %d full-size launches of the region)" % (ctx.get_option("block"), a.batch, len(full)),
+                "kernel": "render_batch (block %d), %d frames per launch (the %d launches of that size in the region)" % (ctx.get_option("block"), per, len(full)),
                 "kernel_ms": round(kern_ms, 4), "algorithmic_flops_per_launch": int(np.mean(alg_flops)),
                 "basis": "FLOPs of the reference-equivalent traversal (every box and triangle test scene.c/bvh.c would run: 22 per box "
                          "test, 50 per triangle test, 45 per ray and mesh) over the kernel's mean HIP-event duration; the peak is a fused "
@@ -536,9 +541,9 @@ def main():
             "config": {"workload": f"{W}x{H} frame, 1 primary ray/pixel + 1 shadow ray/hit pixel, 3 meshes (3625 triangles)",
                        "frames": f"step k of a rank renders entry ({FRAME_STRIDE} k) mod L of its L frames of the 96-frame animation: "
                                  "an even sample of the animation for any --steps",
-                       "frames_per_rank": a.steps, "frames_per_launch": a.batch, "untimed_settling_launches": SETTLE,
+                       "frames_per_rank": a.steps, "frames_per_launch": per, "launch_sizes": sizes, "untimed_settling_launches": SETTLE,
                        "sharding": "frame f on rank f mod N" if world > 1 else "single GPU",
-                       "gather": f"RGB8 framebuffers to rank 0 over {transport}, {a.batch} frames per message" if grouped else "none",
+                       "gather": f"RGB8 framebuffers to rank 0 over {transport}, {per} frames per message" if grouped else "none",
                        "world_size": dist.get_world_size() if grouped else 1,
                        "backend": (dist.get_backend() if grouped else None),
                        "rank_devices": rank_devices,

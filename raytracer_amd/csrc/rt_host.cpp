@@ -377,11 +377,11 @@ bool runs_fast(const rt_ctx* ctx, uint32_t flags) { return ctx->fast && !(flags 
 // index the records in the reference's order.
 void enter_loose_tree(const DeviceMesh& dm, MeshArgs& M) {
     if (!dm.d_loose_tris) return;
+    if (M.grid_axis >= 4u) return;          // a mesh with a tree in a sheared frame keeps it: that tree prunes more than the loose one
     M.root_ref = M.ref_root = dm.loose_root;
     M.pair_count = dm.loose_pairs;
     M.tris = dm.d_loose_tris;
     M.res_pairs = M.res_tris = kNotResident;
-    if (M.grid_axis >= 4u) { M.grid_axis = 3u; M.grid = nullptr; }      // the sheared tree's records name the reference's leaves
 }
 
 // Per-frame constants: camera basis, light, and each mesh's placement (inverse matrices, camera

@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(BLOCK, DEPTH <= 16 ? kBatchWaves : 5) render_b
     __shared__ uint32_t lds_stack[DEPTH * BLOCK];
     LdsStack<BLOCK> stack;
     stack.init(&lds_stack[threadIdx.x]);
-    GlobalNodes nodes; nodes.all = S.pairs;
+    BatchNodes nodes; nodes.all = S.pairs;
 
     int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)));
     // Workgroups go to the 8 XCDs round robin.  With one wave per workgroup, transposing every run

@@ -135,8 +135,15 @@ struct GlobalNodes {
     RT_HD TriRec tri(const MeshArgs& M, uint32_t index) const { return read_tri(M.tris, index); }
 };
 
+// The same source for a kernel that reads its frame constants from memory (rt_render_frames): its walks may use the per-frame
+// part of a sheared tree's gate (shear_gate).
+struct BatchNodes : GlobalNodes {};
+template <class Nodes> struct FrameMasks { static constexpr bool on = false; };
+template <> struct FrameMasks<BatchNodes> { static constexpr bool on = true; };
+
 #if defined(__HIP_DEVICE_COMPILE__)
 template <> struct ScalarNodes<GlobalNodes> { static constexpr bool on = true; __device__ static const PairNode* base(const GlobalNodes& n) { return n.all; } };
+template <> struct ScalarNodes<BatchNodes> { static constexpr bool on = true; __device__ static const PairNode* base(const BatchNodes& n) { return n.all; } };
 #endif
 
 // Distance culling (used unless the caller asks for the reference's visiting order).
@@ -351,6 +358,9 @@ RT_HD int lowest_bit(uint64_t v) {
 // Per frame the host has answered part of the question (shear_frame_masks in rt_pack.h): for the shadow rays' common direction
 // MeshArgs::lit_d it names the close families outright, and for rays from MeshArgs::cam_o it names the families that any ray
 // through the root box can come close to at all -- the others are not looked at.
+// MASKS = false leaves the host's answers alone and looks at every family (kernels that get their frame constants by value
+// would copy all of them to memory for the sake of these few words).
+template <bool MASKS>
 RT_HD bool shear_gate(const MeshArgs& M, F3 o, F3 d, uint64_t& close) {
     const f32x4 h0 = read_uniform4(M.grid, 0), h1 = read_uniform4(M.grid, 4), h2 = read_uniform4(M.grid, 8);
     const float reach = h0.x, origin_factor = h0.y, radius = h0.z;
@@ -361,7 +371,7 @@ RT_HD bool shear_gate(const MeshArgs& M, F3 o, F3 d, uint64_t& close) {
     const bool outside = o.x < h0.w - wide || o.y < h1.x - wide || o.z < h1.y - wide ||
                          o.x > h1.z + wide || o.y > h1.w + wide || o.z > h2.x + wide;
     if (!outside) return false;
-    const uint32_t valid = f32_as_uint(M.grid_slack[0]);
+    const uint32_t valid = MASKS ? f32_as_uint(M.grid_slack[0]) : 0u;
     if ((valid & 2u) && f32_as_uint(d.x) == f32_as_uint(M.lit_d[0]) && f32_as_uint(d.y) == f32_as_uint(M.lit_d[1]) &&
         f32_as_uint(d.z) == f32_as_uint(M.lit_d[2])) {
         close = (uint64_t)f32_as_uint(M.grid_inv[0]) | ((uint64_t)f32_as_uint(M.grid_inv[1]) << 32);
@@ -437,7 +447,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
             // lists of one record, whose own box test is the reference's for that leaf
             uint64_t close;
             const F3 sd = shear(d, M.grid_axis - 4u);
-            if (shear_gate(M, o, d, close) && bits_set(close) <= 3 && sd.x != 0.0f && sd.y != 0.0f && sd.z != 0.0f) {
+            if (shear_gate<FrameMasks<Nodes>::on>(M, o, d, close) && bits_set(close) <= 3 && sd.x != 0.0f && sd.y != 0.0f && sd.z != 0.0f) {
                 sr = slab_ray(shear(o, M.grid_axis - 4u), recip(sd));
                 ref = M.shear_root;
                 apart = close;
@@ -447,7 +457,9 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
         // A list of leaves (a flat mesh's cell, a leaf of a sheared tree): each one's own box test (the reference reaches a leaf
         // exactly when that passes, the boxes above contain it), then its triangles.  True when an any-hit query may stop.
         // `only`: the triangles of the leaf to look at (a mask like the record's own)
-        auto run_record = [&](const size_t at, const uint32_t only) -> bool {
+        // (always inlined: a call would take the address of everything captured, the mesh's constants among them, and a kernel
+        // that gets its frame constants by value would have to copy them to memory first)
+        auto run_record = [&](const size_t at, const uint32_t only) __attribute__((always_inline)) -> bool {
             {
                 float bmin[3], bmax[3];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -466,7 +478,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
                 return test_leaf<ANY, COUNT, FULL, LB>(M, nodes, leaf, o, d, q, work, mask);
             }
         };
-        auto run_list = [&](const uint32_t list) -> bool {
+        auto run_list = [&](const uint32_t list) __attribute__((always_inline)) -> bool {
             const uint32_t count = (list >> 24) & 0xFu;
             const size_t first = lists_at + (size_t)(list & 0x00FFFFFFu) * 8;
             for (uint32_t i = 0; i < count; i++)
@@ -490,7 +502,7 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
         }
         bool live = true;
         while (live) {
-            auto step = [&](const PairNode& N) {
+            auto step = [&](const PairNode& N) __attribute__((always_inline)) {
                 if (COUNT) work.slabs += 2;
                 float tl, tr;
                 bool hl, hr;

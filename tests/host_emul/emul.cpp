@@ -199,7 +199,7 @@ long long emul_shear_masks_hold(void* sp, int mesh, const rt_camera* cam, const 
             float entry;
             if (!slab_t(f3(M.cam_o), recip(ld), M.root_min, M.root_max, entry)) continue;
             uint64_t full = 0, masked = 0;
-            const bool a = shear_gate(plain, f3(M.cam_o), ld, full), b = shear_gate(M, f3(M.cam_o), ld, masked);
+            const bool a = shear_gate<false>(plain, f3(M.cam_o), ld, full), b = shear_gate<true>(M, f3(M.cam_o), ld, masked);
             if (a != b) { bad++; continue; }
             if (!a) continue;
             n++;
@@ -209,7 +209,7 @@ long long emul_shear_masks_hold(void* sp, int mesh, const rt_camera* cam, const 
     // the shadow direction, from an origin the gate admits
     const F3 o = f3(M.cam_o);
     uint64_t full = 0, masked = 0;
-    const bool a = shear_gate(plain, o, f3(M.lit_d), full), b = shear_gate(M, o, f3(M.lit_d), masked);
+    const bool a = shear_gate<false>(plain, o, f3(M.lit_d), full), b = shear_gate<true>(M, o, f3(M.lit_d), masked);
     if (a != b || (a && (full & ~masked))) bad++;
     if (a) n++;
     *looked = n; *spared = skipped;
@@ -277,9 +277,8 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
         M.tris = E.pk.tris.data(); M.attrs = E.pk.attrs.data(); M.texels = E.texels.data();
         memcpy(M.root_min, E.pk.root_min, 12); memcpy(M.root_max, E.pk.root_max, 12);
         M.root_ref = E.pk.root_ref; M.ref_root = E.pk.ref_root;
-        if (s->loose && !E.pk.loose_tris.empty()) { M.root_ref = M.ref_root = E.pk.loose_root; M.tris = E.pk.loose_tris.data(); }
+        if (s->loose && !E.pk.loose_tris.empty() && E.pk.grid_axis < 4) { M.root_ref = M.ref_root = E.pk.loose_root; M.tris = E.pk.loose_tris.data(); }
         set_grid_args(E.pk, E.pk.grid.data(), M); M.tex_w = E.tw; M.tex_h = E.th; M.empty = E.pk.empty ? 1u : 0u; M.wide = E.pk.wide ? 1u : 0u;
-        if (s->loose && M.grid_axis >= 4u) { M.grid_axis = 3u; M.grid = nullptr; }
         fill_placement(tfs[m], A, M);
         shear_frame_masks(E.pk.grid.data(), M);
         mesh_screen_rect(tfs[m], M.root_min, M.root_max, A, A.vis[m]);
@@ -300,6 +299,7 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
     for (int m = 0; m < n_tf && s->vis_shrink; m++)
         for (int32_t* r : {A.vis[m], A.vis_shadow[m]}) { r[0] += s->vis_shrink; r[1] += s->vis_shrink; r[2] -= s->vis_shrink; r[3] -= s->vis_shrink; }
     GlobalNodes nodes; nodes.all = s->all_pairs.data();
+    BatchNodes batch_nodes; batch_nodes.all = s->all_pairs.data();       // rt_render_frames' kernel: with the per-frame part of the gate
     unsigned long long c_slab = 0, c_tri = 0, c_hit = 0, c_dark = 0;
     int high = 0;
     CheckTotals checks;
@@ -315,7 +315,7 @@ int emul_render(void* sp, const rt_camera* cam, const rt_light* light, const rt_
             PixelOut r = full == 1 ? shade_pixel<true, true, false>(A, nodes, Solo(), x, y, st, w)
                        : full == 2 ? shade_pixel<false, false, false>(A, nodes, Solo(), x, y, st, w)
                        : full == 3 ? shade_pixel<false, false, false>(A, nodes, SoloVerify(), x, y, st, w)
-                       : full == 4 ? shade_pixel<false, false, false>(A, nodes, Solo(), x, y, st, w, true)
+                       : full == 4 ? shade_pixel<false, false, false>(A, batch_nodes, Solo(), x, y, st, w, true)
                                    : shade_pixel<true, false, false>(A, nodes, Solo(), x, y, st, w);
             row.add(w);
             const size_t p = (size_t)y * width + x;

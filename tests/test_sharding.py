@@ -260,14 +260,15 @@ def test_bench_starts_its_own_ranks_when_given_a_gpu_count():
 
 def test_bench_eight_ranks_as_the_first_multi_gpu_command_will_run():
     """`python bench.py --gpus 8 --steps 20 --warmup 5` at the bench's own frame size, rehearsed on byte patterns over gloo: eight
-    ranks report, every rank deals itself 12 frames (batches of 8 + 8 + 4 per repetition, a ring of three gathers in flight), and
+    ranks report, every rank deals itself 12 frames (batches of 7 + 7 + 6 per repetition, a ring of three gathers in flight), and
     rank 0 checks every pixel of every frame of every gathered batch against the byte its frame number gives it."""
     import json
     r = _run_bench("--gpus", "8", "--rehearse-cpu", "--steps", "20", "--warmup", "5", timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 8 and out["config"]["world_size"] == 8 and out["config"]["rank_devices"] == ["cpu"] * 8
-    assert out["config"]["frames_per_launch"] == 8 and out["config"]["gathered_frames_equal_rank0_render"] is True
+    assert out["config"]["frames_per_launch"] == 7 and out["config"]["launch_sizes"] == [7, 7, 6]
+    assert out["config"]["gathered_frames_equal_rank0_render"] is True
     reps = out["timing"]["repeats"]
     assert reps >= 3 and out["config"]["rehearsal_frames_checked_on_rank0"] == 8 * 20 * reps
     assert out["config"]["rehearsal_frames_right"] == out["config"]["rehearsal_frames_checked_on_rank0"]
