@@ -779,6 +779,9 @@ private:
         out_.grid_n = (int32_t)n_dir;
         out_.shear_root = root + shift;
         out_.shear_pairs = (uint32_t)tree.size();
+        // A mesh that gains from this tree is made of needles, and a needle's computed distance is the least certain thing
+        // about it (the last bound above): nothing of such a mesh is skipped for being farther away than the closest hit.
+        out_.wide = true;
         if (deepest > out_.depth) out_.depth = deepest;
     }
 
