@@ -351,7 +351,9 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * frame; 0 = four tile rows), "xcd_swizzle" (rt_render_frames: 1 = each XCD gets runs of eight neighbouring
  * tiles, default; 0 = every eighth tile), "device_build_min" (see rt_mesh_upload_soup), "regroup" (1, default: a mesh uploaded through the host
  * packer gets a second tree over the reference's own leaves, split by surface area, which rays enter instead of the
- * reference's mean-split tree; the leaves reached, and every output, are the same; 0 = the reference's tree only;
+ * reference's mean-split tree, and, where the mesh is made of long thin triangles along the diagonals of a coordinate plane, a
+ * further one whose boxes live in the frame sheared by 45 degrees in that plane; the leaves whose triangles get tested are
+ * fewer, the triangles accepted, and every output, are the same; 0 = the reference's tree only;
  * applies to meshes uploaded afterwards), "sampled_split" (rt_render_frame_sampled with four samples or
  * more: the samples of a tile are traced by four waves and added up in order instead of one wave looping
  * over them -- 0 never, 1 when the launch has fewer than 100 000 tiles (default), 2 always),
