@@ -121,7 +121,10 @@ struct ShearHeader {
     float hull_min[3], hull_max[3];
     uint32_t lists_at;       // first word of the leaf records (a multiple of eight)
     uint32_t members_at;     // first word of the members
-    uint32_t pad[5];
+    uint32_t near_root;      // a second tree over the same records for rays that start inside the widened hull: every box wider by how
+                             // far such an origin can lie behind a plane and still have its triangle accepted
+    float near_reach;        // ... for origins with |o| <= near_reach
+    uint32_t pad[3];
 };
 static_assert(sizeof(ShearHeader) == 64, "ShearHeader is sixteen words");
 constexpr uint32_t kGridListMax = 8;

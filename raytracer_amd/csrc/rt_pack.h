@@ -637,7 +637,7 @@ private:
         if (!(radius >= 1e-6)) return;
         const double S = radius + kShearBeyond;
         const double pad_uv = radius / 128.0;              // how far outside the two edges at v0 a widened triangle may reach at most
-        struct Widened { double corner[3][3]; };
+        struct Widened { double corner[3][3]; double behind; };    // behind: how far behind the origin, per unit of S, the plane may lie
         std::vector<Widened> widened(out_.tris.size());
         struct Direction { double n[3]; double c; std::map<uint32_t, uint32_t> members; };   // leaf (its place in leaves_) -> mask of its triangles
         std::vector<Direction> directions;
@@ -666,6 +666,7 @@ private:
                 const double eps_u = 24.0 * U * S * l2 / (n2 * c), eps_v = 24.0 * U * S * l1 / (n2 * c);
                 const double eps_3 = 24.0 * U * (q + S * p) / c + 8.0 * U;
                 origin_factor = std::max(origin_factor, 24.0 * U * q / c);
+                widened[i].behind = 24.0 * U * q / c;
                 const double bary[3][2] = {{-eps_u, -eps_v}, {1.0 + eps_3 + eps_v, -eps_v}, {-eps_u, 1.0 + eps_3 + eps_u}};
                 for (int k = 0; k < 3; k++)
                     for (int a = 0; a < 3; a++) {
@@ -723,6 +724,7 @@ private:
         if (out_.pairs.size() + leaves_.size() >= (size_t)kGridListBit) return;
         // records, in the order of leaves_ as it stands now; the tree is built over copies that regroup_range may reorder
         std::vector<LeafItem> records = leaves_;
+        const std::vector<LeafItem> best_items_copy = best_items;            // item j belongs to record j; regroup_range reorders its input
         leaves_.swap(best_items);
         int balanced = 1;
         while (((size_t)1 << balanced) < leaves_.size()) balanced++;
@@ -732,6 +734,26 @@ private:
         int deepest = 0;
         float lo[3], hi[3];
         const uint32_t root = regroup_range(tree, 0, 0, leaves_.size(), 0, deepest, lo, hi);
+        // The same once more for rays that start inside the hull (a shadow ray leaving the mesh's own surface): there the plane
+        // of a triangle may lie behind the origin by up to `behind` * S and the triangle still be accepted, so every box gets
+        // that much room on all sides (sqrt(2) of it along the sheared axes) -- then it holds the origin whenever that happens,
+        // and a box that holds the origin passes the slab test.  S is bounded by letting in origins with |o| <= near_reach only.
+        const double near_reach = 1.5 * radius;
+        std::vector<LeafItem> near_items(records.size());
+        for (size_t j = 0; j < records.size(); j++) {
+            const uint32_t first = records[j].ref & 0x00FFFFFFu, count = (records[j].ref >> 24) & 0x7Fu;
+            double behind = 0.0;
+            for (uint32_t i = first; i < first + count; i++) behind = std::max(behind, widened[i].behind);
+            const double more = std::sqrt(2.0) * behind * (near_reach + radius) * 1.0001;
+            near_items[j] = best_items_copy[j];
+            for (int a = 0; a < 3; a++) { near_items[j].lo[a] = round_down((double)near_items[j].lo[a] - more); near_items[j].hi[a] = round_up((double)near_items[j].hi[a] + more); }
+        }
+        leaves_.swap(near_items);
+        std::vector<PairNode> near_tree(leaves_.size() - 1);
+        int near_deepest = 0;
+        const uint32_t near_root = regroup_range(near_tree, 0, 0, leaves_.size(), 0, near_deepest, lo, hi);
+        leaves_.swap(near_items);
+        const bool near_ok = !(near_root & (kLeafBit | kGridListBit)) && near_deepest + 2 <= kStackDepth && near_deepest <= RT_MAX_TREE_DEPTH;
         depth_cap_ = RT_MAX_TREE_DEPTH;
         leaves_.swap(records);                                              // leaves_ as before; `records` is scratch from here on
         if ((root & (kLeafBit | kGridListBit)) || deepest + 2 > kStackDepth || deepest > RT_MAX_TREE_DEPTH) return;
@@ -740,6 +762,15 @@ private:
             if (!(p.lref & (kLeafBit | kGridListBit))) p.lref += shift;
             if (!(p.rref & (kLeafBit | kGridListBit))) p.rref += shift;
             out_.pairs.push_back(p);
+        }
+        const uint32_t near_shift = (uint32_t)out_.pairs.size();
+        if (near_ok) {
+            for (PairNode p : near_tree) {
+                if (!(p.lref & (kLeafBit | kGridListBit))) p.lref += near_shift;
+                if (!(p.rref & (kLeafBit | kGridListBit))) p.rref += near_shift;
+                out_.pairs.push_back(p);
+            }
+            if (near_deepest > deepest) deepest = near_deepest;
         }
         // header, directions, records
         const size_t n_dir = directions.size();
@@ -754,6 +785,8 @@ private:
         header.origin_factor = round_up(origin_factor * 1.0001);
         header.radius = round_up(radius);
         for (int a = 0; a < 3; a++) { header.hull_min[a] = round_down(hull_lo[a]); header.hull_max[a] = round_up(hull_hi[a]); }
+        header.near_root = near_ok ? near_root + near_shift : 0u;
+        header.near_reach = near_ok ? round_down(near_reach) : 0.0f;          // 0: there is no such tree
         header.lists_at = (uint32_t)rec_base;
         header.members_at = (uint32_t)members_at;
         memcpy(out_.grid.data(), &header, sizeof header);
@@ -778,7 +811,7 @@ private:
         out_.grid_axis = 4u + (uint32_t)best_k;
         out_.grid_n = (int32_t)n_dir;
         out_.shear_root = root + shift;
-        out_.shear_pairs = (uint32_t)tree.size();
+        out_.shear_pairs = (uint32_t)(tree.size() + (near_ok ? near_tree.size() : 0));
         // A mesh that gains from this tree is made of needles, and a needle's computed distance is the least certain thing
         // about it (the last bound above): nothing of such a mesh is skipped for being farther away than the closest hit.
         out_.wide = true;

@@ -360,17 +360,24 @@ RT_HD int lowest_bit(uint64_t v) {
 // through the root box can come close to at all -- the others are not looked at.
 // MASKS = false leaves the host's answers alone and looks at every family (kernels that get their frame constants by value
 // would copy all of them to memory for the sake of these few words).
+// `root` gets the tree to walk: MeshArgs::shear_root, or, for an origin inside the widened hull but no farther out than
+// ShearHeader::near_reach, the tree whose boxes have room for such origins.
 template <bool MASKS>
-RT_HD bool shear_gate(const MeshArgs& M, F3 o, F3 d, uint64_t& close) {
+RT_HD bool shear_gate(const MeshArgs& M, F3 o, F3 d, uint64_t& close, uint32_t& root) {
     const f32x4 h0 = read_uniform4(M.grid, 0), h1 = read_uniform4(M.grid, 4), h2 = read_uniform4(M.grid, 8);
     const float reach = h0.x, origin_factor = h0.y, radius = h0.z;
     const float oo = dot(o, o), dd = dot(d, d);
     close = 0;
+    root = M.shear_root;
     if (!(oo <= reach * reach) || !(fabsf(dd - 1.0f) <= 0.0009765625f)) return false;
     const float wide = origin_factor * (sqrtf(oo) + radius);
     const bool outside = o.x < h0.w - wide || o.y < h1.x - wide || o.z < h1.y - wide ||
                          o.x > h1.z + wide || o.y > h1.w + wide || o.z > h2.x + wide;
-    if (!outside) return false;
+    if (!outside) {
+        const f32x4 h3 = read_uniform4(M.grid, 12);
+        if (!(h3.x > 0.0f && oo <= h3.x * h3.x)) return false;
+        root = f32_as_uint(h2.w);
+    }
     const uint32_t valid = MASKS ? f32_as_uint(M.grid_slack[0]) : 0u;
     if ((valid & 2u) && f32_as_uint(d.x) == f32_as_uint(M.lit_d[0]) && f32_as_uint(d.y) == f32_as_uint(M.lit_d[1]) &&
         f32_as_uint(d.z) == f32_as_uint(M.lit_d[2])) {
@@ -446,10 +453,11 @@ RT_HD bool trace_mesh(const MeshArgs& M, const Nodes& nodes, F3 o, F3 d, F3 inv,
             // the tree in the sheared frame: same records, same slab arithmetic, on the sheared ray (same t); its leaves are
             // lists of one record, whose own box test is the reference's for that leaf
             uint64_t close;
+            uint32_t root;
             const F3 sd = shear(d, M.grid_axis - 4u);
-            if (shear_gate<FrameMasks<Nodes>::on>(M, o, d, close) && bits_set(close) <= 3 && sd.x != 0.0f && sd.y != 0.0f && sd.z != 0.0f) {
+            if (shear_gate<FrameMasks<Nodes>::on>(M, o, d, close, root) && bits_set(close) <= 3 && sd.x != 0.0f && sd.y != 0.0f && sd.z != 0.0f) {
                 sr = slab_ray(shear(o, M.grid_axis - 4u), recip(sd));
-                ref = M.shear_root;
+                ref = root;
                 apart = close;
             }
         }

@@ -199,7 +199,8 @@ long long emul_shear_masks_hold(void* sp, int mesh, const rt_camera* cam, const 
             float entry;
             if (!slab_t(f3(M.cam_o), recip(ld), M.root_min, M.root_max, entry)) continue;
             uint64_t full = 0, masked = 0;
-            const bool a = shear_gate<false>(plain, f3(M.cam_o), ld, full), b = shear_gate<true>(M, f3(M.cam_o), ld, masked);
+            uint32_t root_a, root_b;
+            const bool a = shear_gate<false>(plain, f3(M.cam_o), ld, full, root_a), b = shear_gate<true>(M, f3(M.cam_o), ld, masked, root_b);
             if (a != b) { bad++; continue; }
             if (!a) continue;
             n++;
@@ -209,7 +210,8 @@ long long emul_shear_masks_hold(void* sp, int mesh, const rt_camera* cam, const 
     // the shadow direction, from an origin the gate admits
     const F3 o = f3(M.cam_o);
     uint64_t full = 0, masked = 0;
-    const bool a = shear_gate<false>(plain, o, f3(M.lit_d), full), b = shear_gate<true>(M, o, f3(M.lit_d), masked);
+    uint32_t root_a, root_b;
+    const bool a = shear_gate<false>(plain, o, f3(M.lit_d), full, root_a), b = shear_gate<true>(M, o, f3(M.lit_d), masked, root_b);
     if (a != b || (a && (full & ~masked))) bad++;
     if (a) n++;
     *looked = n; *spared = skipped;
