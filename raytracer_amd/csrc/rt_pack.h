@@ -744,7 +744,7 @@ private:
             const uint32_t first = records[j].ref & 0x00FFFFFFu, count = (records[j].ref >> 24) & 0x7Fu;
             double behind = 0.0;
             for (uint32_t i = first; i < first + count; i++) behind = std::max(behind, widened[i].behind);
-            const double more = std::sqrt(2.0) * behind * (near_reach + radius) * 1.0001;
+            const double more = std::sqrt(2.0) * behind * (near_reach + radius) * 1.001;       // 1.001: |d| may differ from 1 by that much
             near_items[j] = best_items_copy[j];
             for (int a = 0; a < 3; a++) { near_items[j].lo[a] = round_down((double)near_items[j].lo[a] - more); near_items[j].hi[a] = round_up((double)near_items[j].hi[a] + more); }
         }
