@@ -492,8 +492,9 @@ def main():
         ctx.set_option("fast", 0)
         fms = [fms[i] for i in full]                                     # the launches `kernel_ms` above is the mean of
         fast = {"kernel_ms": round(float(np.mean(fms)), 4), "speedup_over_exact_kernel": round(kern_ms / float(np.mean(fms)), 3),
-                "note": "option \"fast\" (not the default, not in `value`): fused arithmetic, and drone and treasure walked through a tree over "
-                        "their triangles themselves (leaves of up to 8 neighbours in tight boxes) instead of the reference's leaves; hit ids equal on "
+                "note": "option \"fast\" (not the default, not in `value`): fused arithmetic, and the treasure walked through a tree over "
+                        "its triangles themselves (leaves of up to 8 neighbours in tight boxes) instead of the reference's leaves (the drone keeps "
+                        "its tree in a sheared frame, which prunes more); hit ids equal on "
                         ">= 99.99 % of camera rays, colours within 1 on >= 99.9 % of pixels"}
         # one frame launched alone (its duration is set by its slowest tiles)
         one = []

@@ -366,7 +366,7 @@ int rt_set_trace_buffer(rt_ctx* ctx, void* d_tile_clock);
  * as one fused multiply-add per bound, and closed meshes walked through a tree over their triangles themselves (leaves of up
  * to eight neighbouring triangles in tight boxes, built beside the other trees at upload when option "regroup" is on) instead
  * of the reference's leaves.  Not bit-exact: hit ids equal on at least 99.99 % of camera rays and 8-bit colours within 1 on at
- * least 99.9 % of pixels against the exact build, which the GPU tests assert; measured 1.3-1.4 times as fast on the animation,
+ * least 99.9 % of pixels against the exact build, which the GPU tests assert; measured 1.2 times as fast on the animation (a mesh with a tree in a sheared frame keeps that tree),
  * 1.5 times on the instanced stress scene.  Calls with RT_FLAG_VERIFY_SKIPS or RT_FLAG_REFERENCE_ORDER run the exact build
  * whatever this option says; rt_render_frame_sampled always does), "instanced_wave" (rt_render_frame_instanced: 0, default = one lane per pixel walks
  * hierarchy, instance and triangles as nested loops; 1..8 = every lane is a state machine and the wave executes the step most of
