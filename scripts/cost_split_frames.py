@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where rt_render_frames spends its time, by leaving parts of the scene out: the whole scene, the ground replaced by two
-triangles (its walk costs nothing then), the ground alone, two triangles alone (the per-pixel fixed part).  ms per launch of
+triangles (its walk costs nothing then), the ground alone, two triangles alone (the per-pixel fixed part), the scene without the drone / without the treasure, each of those two alone.  ms per launch of
 8 frames at 1920x1080 over the bench's twelve launches.  Run on a GPU: python scripts/cost_split_frames.py"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,5 +41,10 @@ with capi.Context(0) as c3:
     c3.clear_scene()
     c3.upload_soup(quad, host_api.mesh_texture(scene.meshes[2]))
     out["two_triangles_alone"] = timeit(c3, scene.camera, scene.light, lambda f: scene.transforms(f)[2:])
+for name, keep in (("without_drone", (1, 2)), ("without_treasure", (0, 2)), ("drone_alone", (0,)), ("treasure_alone", (1,))):
+    with capi.Context(0) as c4:
+        for k in keep:
+            c4.upload_host_mesh(scene.meshes[k])
+        out[name] = timeit(c4, scene.camera, scene.light, lambda f: [scene.transforms(f)[k] for k in keep])
 print(json.dumps(out))
 scene.close()
